@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the FLUX-VAE encode+tag hot path on N MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic batch per GPU: fp32 NCHW images resident in
+HBM -> vt_encode_tag (HIP encoder + decoder) -> [B,N] logits -> (N>1) one RCCL all-gather of logits.
+Workload at N=1: BASELINE.json configs[2] -- batch 16, 1024x1024, 8-head attention decoder, 10k tags,
+bf16 MFMA operands / fp32 accumulate.  Weak scaling: the per-GPU batch is fixed as N grows.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the implicit-GEMM MFMA conv):
+achieved = its algorithmic FLOPs / its summed launch durations, from HIP events recorded on the launch
+stream inside the timed region (vt_profile_begin/end in the C ABI).  `cpu_baseline` times the CPU
+oracle (oracle/, kind "port") on this box's host cores, rank 0, N=1 only, on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (not the 2:1-sparse headline)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    p.add_argument("--height", type=int, default=1024)
+    p.add_argument("--width", type=int, default=1024)
+    p.add_argument("--tags", type=int, default=10000)
+    p.add_argument("--encode-only", action="store_true", help="BASELINE configs[1]: encoder only")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-res", type=int, default=1024)
+    return p.parse_args()
+
+
+def cpu_baseline(res, tags, flops_target):
+    """CPU oracle (torch fp32 restatement of the reference path) on the host cores: one image."""
+    import torch
+    from oracle import decoder_ref, encoder_ref
+    from vae_tagger_amd import synth
+    cores = torch.get_num_threads()
+    sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(tags), seed=1)
+    x = synth.synth_images(1, res, res, seed=0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        lat = encoder_ref.vae_wrapper_encode(sd_e, x)
+        decoder_ref.get_confidence(decoder_ref.attention_decoder_forward(sd_d, lat))
+        dt = time.perf_counter() - t0
+    scale = encoder_ref.encoder_flops(res, res) / flops_target
+    return {"value": round(scale / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 image {res}x{res} encode+tag, fp32 torch CPU oracle, one timed run ({dt:.1f} s)"
+                      + ("" if abs(scale - 1) < 1e-9 else f", scaled by FLOP ratio {scale:.4f} to the benchmark shape")}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    from vae_tagger_amd import sharding, synth
+    from vae_tagger_amd.diffusers_vae_loader import (DiffusersVAEWrapper, get_diffusers_vae_config,
+                                                      load_diffusers_vae_from_config)
+    from vae_tagger_amd.modules import create_attention_decoder
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+
+    vae = load_diffusers_vae_from_config(get_diffusers_vae_config())
+    vae.load_state_dict(synth.synth_state_dict(synth.encoder_manifest(), seed=0), strict=False)
+    vae_model = DiffusersVAEWrapper(vae).to(dev).eval()
+    dec = create_attention_decoder(16, a.height // 8, a.width // 8, a.tags,
+                                   {"use_spatial_attention": True, "use_self_attention": True,
+                                    "use_cross_attention": False, "attention_heads": 8})
+    dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(a.tags), seed=1), strict=False)
+    dec = dec.to(dev).eval()
+    pipe = EncodeTagPipeline(vae_model, dec)
+
+    B = a.batch
+    # synthetic inputs, resident in HBM before the timed region; distinct per rank (global batch = world*B)
+    x = synth.synth_images(B, a.height, a.width, seed=1000 + rank).to(dev)
+    counts = [B] * world
+
+    def step():
+        if a.encode_only:
+            return vae_model.encode(x)
+        logits = pipe.logits(x)
+        return sharding.all_gather_logits(logits, counts) if world > 1 else logits
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof_ctx = pipe.ctx if not a.encode_only else vae._context()
+    prof_ctx.call("vt_profile_begin")
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n = 3
+    launches = (ctypes.c_longlong * n)()
+    tot_ms = (ctypes.c_double * n)()
+    tot_fl = (ctypes.c_double * n)()
+    names = (ctypes.c_char_p * n)()
+    prof_ctx.call("vt_profile_end", n, launches, tot_ms, tot_fl, names)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        flops_img = pipe.flops_per_image(a.height, a.width)
+        ips = world * B * a.steps / elapsed
+        dom = max(range(n), key=lambda i: tot_ms[i])
+        achieved = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
+        gemm_ms = sum(tot_ms)
+        res = {
+            "metric": "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16",
+            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("configs[2]: " if not a.encode_only else "configs[1]: ")
+                       + f"batch {B}/GPU {a.width}x{a.height} FLUX-VAE encode"
+                       + ("" if a.encode_only else f" + 8-head attention decoder, {a.tags} tags")
+                       + ", random-init weights (seeded), fp32 NCHW input resident in HBM",
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "tflop_per_image": round(flops_img / 1e12, 4),
+                       "end_to_end_tflops_per_gpu": round(ips / world * flops_img / 1e12, 2),
+                       "end_to_end_frac_of_mfma_peak": round(ips / world * flops_img / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)},
+            "roofline": {"bound": "mfma", "kernel": names[dom].decode(), "achieved": round(achieved, 2),
+                         "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches": int(launches[dom]),
+                         "avg_launch_ms": round(tot_ms[dom] / max(1, launches[dom]), 4),
+                         "all_mfma_kernels_share_of_step": round(gemm_ms / (elapsed * 1e3), 4),
+                         "per_config": {names[i].decode(): {"launches": int(launches[i]), "ms": round(tot_ms[i], 3),
+                                                            "tflops": round(tot_fl[i] / max(tot_ms[i], 1e-9) / 1e9, 2)}
+                                        for i in range(n)}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.cpu_sample_res, a.tags, flops_img)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+/*
+ * vae_tagger_hip.h -- C ABI of libvae_tagger_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the inference hot path of spawner1145/vae-tagger.  The reference has no
+ * FFI of its own: the boundary is a Python object protocol.  Each entry
+ * point below names the reference call it stands in for; INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain C types only; every buffer is caller-owned DEVICE memory unless marked "host";
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); no call synchronises the host;
+ *   - every call returns VT_OK or an error code; vt_last_error(ctx) gives the message; nothing aborts;
+ *   - one context per device / thread; no global state;
+ *   - workspace is caller-provided (query the *_workspace_bytes function first), 256-B aligned.
+ */
+#ifndef VAE_TAGGER_HIP_H
+#define VAE_TAGGER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vt_context vt_context;
+
+enum { VT_OK = 0, VT_ERR_INVALID = 1, VT_ERR_HIP = 2, VT_ERR_STATE = 3, VT_ERR_MISSING_WEIGHT = 4,
+       VT_ERR_WORKSPACE = 5 };
+enum { VT_F32 = 0, VT_BF16 = 1, VT_F16 = 2 };
+
+const char* vt_version(void);
+int vt_create(int device, vt_context** out);
+void vt_destroy(vt_context* ctx);
+const char* vt_last_error(const vt_context* ctx);
+
+/* ---- model construction --------------------------------------------------------------------
+ * vt_encoder_configure   <- AutoencoderKL(...) hyper-parameters, diffusers_vae_loader.py:8-35
+ * vt_set_weight          <- vae.load_state_dict(state_dict, strict=False), diffusers_vae_loader.py:44
+ *                           and decoder.load_state_dict(...), infer_full.py:63.  `name` is the
+ *                           state-dict key (diffusers / reference naming); `data` is a HOST pointer.
+ * vt_encoder_finalize    packs weights for the MFMA kernels ([Cout][tap][Cin] bf16) and uploads them.
+ * vt_decoder_configure   <- create_attention_decoder / ClassificationDecoder, infer_full.py:42-58
+ */
+int vt_encoder_configure(vt_context* ctx, int in_channels, int latent_channels, const int* block_out_channels,
+                         int n_blocks, int layers_per_block, int norm_num_groups, float scaling_factor,
+                         int has_scaling_factor, float shift_factor, int has_shift_factor);
+int vt_set_weight(vt_context* ctx, const char* name, const void* host_data, int dtype, const int64_t* shape,
+                  int ndim);
+int vt_encoder_finalize(vt_context* ctx);
+int vt_decoder_configure(vt_context* ctx, int num_classes, int latent_channels, int plain_decoder,
+                         int use_spatial_attention, int use_self_attention, int use_cross_attention,
+                         int attention_heads);
+int vt_decoder_finalize(vt_context* ctx);
+
+/* ---- hot path ------------------------------------------------------------------------------
+ * vt_encode          <- DiffusersVAEWrapper.encode(x), diffusers_vae_loader.py:78-86:
+ *                       vae.encode(x).latent_dist.mode() * scaling_factor + shift_factor.
+ *                       x: fp32 NCHW [B,3,H,W] in [-1,1].  mode selects what is written (fp32 NCHW):
+ *                         0: moments [B,2*latent,H/8,W/8] (mean | logvar) -- AutoencoderKL.encode surface
+ *                         1: latent_dist.mode() = mean [B,latent,H/8,W/8]
+ *                         2: mode() * scaling_factor + shift_factor -- DiffusersVAEWrapper.encode
+ * vt_decode_logits   <- decoder.forward(latent), modules.py:424-468 / :333-349 -> fp32 [B,N]
+ * vt_get_confidence  <- sigmoid + descending sort, modules.py:470-475 (ties: ascending tag index)
+ * vt_encode_tag      <- the loop body of infer_full.py:101-105 for a whole batch
+ */
+size_t vt_encode_workspace_bytes(const vt_context* ctx, int B, int H, int W);
+int vt_encode(vt_context* ctx, const float* x_nchw, int B, int H, int W, int mode, float* latent_out,
+              void* workspace, size_t workspace_bytes, void* stream);
+size_t vt_decode_workspace_bytes(const vt_context* ctx, int B, int h, int w);
+int vt_decode_logits(vt_context* ctx, const float* latent_nchw, int B, int h, int w, float* logits_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int vt_get_confidence(vt_context* ctx, const float* logits, int B, int N, float* conf_sorted_out,
+                      int64_t* indices_out, void* stream);
+size_t vt_encode_tag_workspace_bytes(const vt_context* ctx, int B, int H, int W);
+int vt_encode_tag(vt_context* ctx, const float* x_nchw, int B, int H, int W, float* latent_out /* may be NULL */,
+                  float* logits_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* algorithmic FLOPs of one encoder forward at HxW -- for roofline reporting */
+double vt_encoder_flops(const vt_context* ctx, int H, int W);
+
+/* ---- measurement ----------------------------------------------------------------------------
+ * Between vt_profile_begin and vt_profile_end every launch of the implicit-GEMM MFMA kernel is
+ * bracketed by hipEvents recorded on the launch stream.  vt_profile_end synchronises on them and
+ * returns, per tile configuration (3 of them), the launch count, summed duration (ms) and summed
+ * ALGORITHMIC FLOPs (2*B*Hout*Wout*Cout*taps*Cin).  bench.py derives roofline.achieved from these.
+ */
+int vt_profile_begin(vt_context* ctx);
+int vt_profile_end(vt_context* ctx, int max_cfg, long long* launches, double* total_ms, double* total_flops,
+                   const char** kernel_names);
+
+/* ---- single operators (parity tests drive each kernel through the same ABI) ------------------
+ * NHWC bf16 activations, weights in the reference's own layouts (fp32 host order is converted by
+ * the caller to bf16 [Cout][kh][kw][Cin]); fp32 accumulate.
+ */
+int vt_op_conv2d(vt_context* ctx, const void* x_bf16_nhwc, const void* w_bf16_ohwi, const float* bias,
+                 const float* residual_f32, float* out_f32, void* out_bf16, int B, int Hin, int Win, int Cin,
+                 int Cout, int ksize, int stride, int pad_lo, int pad_hi, void* stream);
+int vt_op_gemm_nt(vt_context* ctx, const void* a_bf16, const void* b_bf16, const float* bias, float* out_f32,
+                  void* out_bf16, int batch, int M, int N, int K, int lda, int ldb, int ldo, long long a_bs,
+                  long long b_bs, long long o_bs, float alpha, int bias_per_row, void* stream);
+int vt_op_conv_in(vt_context* ctx, const float* x_nchw, const float* w_oihw, const float* bias, float* out_f32,
+                  void* out_bf16, int B, int H, int W, int Cout, void* workspace, void* stream);
+size_t vt_op_groupnorm_workspace_bytes(int B, int HW, int C);
+int vt_op_groupnorm(vt_context* ctx, const void* x, int x_dtype, int B, int HW, int C, int groups, float eps,
+                    const float* gamma, const float* beta, int silu, void* y_bf16, void* workspace, void* stream);
+int vt_op_softmax_rows(vt_context* ctx, const float* scores, void* probs_bf16, int rows, int n, int lds, int ldp,
+                       void* stream);
+size_t vt_op_attention_workspace_bytes(int B, int S, int C);
+int vt_op_attention(vt_context* ctx, const void* x_bf16 /* [B][S][C] normed tokens */, const float* residual_f32,
+                    float* out_f32, int B, int S, int C, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAE_TAGGER_HIP_H */

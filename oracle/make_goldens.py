@@ -1,0 +1,117 @@
+"""Generate tests/golden/*.npz.  Run in the build container only:
+
+    PYTHONDONTWRITEBYTECODE=1 python -B oracle/make_goldens.py
+
+Decoder fixtures are OUTPUTS OF THE REFERENCE ITSELF: /root/reference/modules.py is imported
+(read-only, with empty stand-in modules for the two packages it imports at top level but the
+decoder classes never touch: torchvision and diffusers -- SURVEY.md section 8c), driven with
+the seeded per-key weights of vae_tagger_amd.synth, and its results are committed as data.
+The restatement in oracle/decoder_ref.py is asserted against them here and again in tests.
+
+Encoder fixtures come from oracle/encoder_ref.py (the reference's encoder arithmetic is the
+absent third-party `diffusers`; parity unpinned, see that file's header).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import decoder_ref, encoder_ref  # noqa: E402
+from vae_tagger_amd import synth  # noqa: E402
+
+DECODER_CASES = [
+    # name, num_classes, latent shape, flags
+    ("attn_n11_16x16", 11, (2, 16, 16, 16), dict(spatial=True, self_attn=True, cross=False)),
+    ("attn_n10000_64x64", 10000, (2, 16, 64, 64), dict(spatial=True, self_attn=True, cross=False)),
+    ("attn_n11_72x128", 11, (1, 16, 72, 128), dict(spatial=True, self_attn=True, cross=False)),
+    ("attn_cross_n11_16x16", 11, (2, 16, 16, 16), dict(spatial=True, self_attn=True, cross=True)),
+    ("attn_nospatial_n11_16x16", 11, (2, 16, 16, 16), dict(spatial=False, self_attn=True, cross=False)),
+    ("plain_n11_16x16", 11, (2, 16, 16, 16), None),
+]
+ENCODER_CASES = [("enc_64x64", 1, 64, 64), ("enc_128x192", 1, 128, 192), ("enc_512x512", 1, 512, 512)]
+
+
+def latent_input(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return 0.1159 + 0.8 * torch.randn(shape, generator=g)
+
+
+def import_reference():
+    for name in ("torchvision", "torchvision.transforms", "diffusers", "diffusers.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["diffusers"].models = sys.modules["diffusers.models"]
+    sys.modules["diffusers.models"].AutoencoderKL = object
+    sys.path.insert(0, "/root/reference")
+    import modules as ref
+    return ref
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = import_reference()
+    torch.set_grad_enabled(False)
+    for name, n, shape, flags in DECODER_CASES:
+        if flags is None:
+            man = synth.plain_decoder_manifest(n)
+            mod = ref.ClassificationDecoder(16, shape[2], shape[3], n)
+        else:
+            man = synth.attention_decoder_manifest(n, 16, flags["spatial"], flags["self_attn"], flags["cross"])
+            mod = ref.create_attention_decoder(16, shape[2], shape[3], n, {
+                "use_spatial_attention": flags["spatial"], "use_self_attention": flags["self_attn"],
+                "use_cross_attention": flags["cross"], "attention_heads": 8})
+        sd = synth.synth_state_dict(man, seed=1)
+        assert set(mod.state_dict().keys()) == set(sd.keys()), (name, set(mod.state_dict()) ^ set(sd))
+        for k, v in mod.state_dict().items():
+            assert tuple(v.shape) == tuple(sd[k].shape), (k, v.shape, sd[k].shape)
+        missing, unexpected = mod.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected
+        mod.eval()
+        x = latent_input(shape, seed=7)
+        logits = mod(x)
+        conf, idx = mod.get_confidence(x)
+        out = {"logits": logits.numpy(), "conf_sorted": conf.numpy(), "indices": idx.numpy(),
+               "input_checksum": np.array([x.double().sum().item(), x.double().abs().sum().item()])}
+        if shape[2] * shape[3] <= 256:
+            out["input"] = x.numpy()
+        if flags is not None:
+            t = x
+            if flags["spatial"]:
+                t = mod.spatial_attention(t)
+                if t.numel() <= 1 << 15:
+                    out["after_spatial"] = t.numpy()
+            t = mod.feature_compress(t)
+            out["after_compress"] = t.numpy()
+            t = mod.self_attention_post(t)
+            out["after_self_attn"] = t.numpy()
+            mine = decoder_ref.attention_decoder_forward(sd, x)
+        else:
+            mine = decoder_ref.plain_decoder_forward(sd, x)
+        err = (mine - logits).abs().max().item()
+        assert err < 1e-4 * max(1.0, logits.abs().max().item()), (name, err)
+        np.savez_compressed(os.path.join(OUT, f"decoder_{name}.npz"), **out)
+        print(f"decoder_{name}: logits {tuple(logits.shape)} |restatement - reference| = {err:.2e}")
+
+    sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    for name, b, h, w in ENCODER_CASES:
+        x = synth.synth_images(b, h, w, seed=3)
+        taps = {}
+        lat = encoder_ref.vae_wrapper_encode(sd, x, taps=taps)
+        out = {"latent": lat.numpy(),
+               "input_checksum": np.array([x.double().sum().item(), x.double().abs().sum().item()])}
+        for k, v in taps.items():
+            out["tap_" + k] = np.array([v.double().mean().item(), v.double().std().item(),
+                                        v.double().abs().max().item()])
+        np.savez_compressed(os.path.join(OUT, f"encoder_{name}.npz"), **out)
+        print(f"encoder_{name}: latent {tuple(lat.shape)} mean {lat.mean():.4f} std {lat.std():.4f} "
+              + " ".join(f"{k}:std={v.std():.3f},max={v.abs().max():.2f}" for k, v in taps.items()))
+
+
+if __name__ == "__main__":
+    main()

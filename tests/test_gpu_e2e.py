@@ -1,0 +1,158 @@
+"""GPU parity of the whole hot path through the reference-shaped Python surface:
+encoder vs the committed goldens / the CPU oracle, decoder vs outputs of the reference itself,
+and size-independent properties at BASELINE.json's full sizes."""
+import pytest
+import torch
+
+from oracle import decoder_ref, encoder_ref
+from vae_tagger_amd import synth
+
+from _util import golden, latent_input
+
+pytestmark = pytest.mark.gpu
+
+TOL_LATENT_BF16 = 1e-2      # north_star: latent / logit tensors within 1e-2 for the bf16 path
+TOL_LOGIT_F32 = 1e-3        # decoder runs in fp32: within 1e-3 (observed ~1e-5)
+
+
+@pytest.fixture(scope="module")
+def vae():
+    from vae_tagger_amd.diffusers_vae_loader import (DiffusersVAEWrapper, get_diffusers_vae_config,
+                                                      load_diffusers_vae_from_config)
+    m = load_diffusers_vae_from_config(get_diffusers_vae_config())
+    missing, unexpected = m.load_state_dict(synth.synth_state_dict(synth.encoder_manifest(), seed=0), strict=False)
+    assert not missing and not unexpected
+    return DiffusersVAEWrapper(m).to("cuda").eval()
+
+
+def _decoder(n, flags=(True, True, False), plain=False):
+    from vae_tagger_amd.modules import ClassificationDecoder, create_attention_decoder
+    if plain:
+        d = ClassificationDecoder(16, 16, 16, n)
+        d.load_state_dict(synth.synth_state_dict(synth.plain_decoder_manifest(n), seed=1), strict=False)
+    else:
+        d = create_attention_decoder(16, 16, 16, n, {"use_spatial_attention": flags[0], "use_self_attention": flags[1],
+                                                     "use_cross_attention": flags[2], "attention_heads": 8})
+        missing, unexpected = d.load_state_dict(
+            synth.synth_state_dict(synth.attention_decoder_manifest(n, 16, *flags), seed=1), strict=False)
+        assert not missing and not unexpected
+    return d.to("cuda").eval()
+
+
+@pytest.mark.parametrize("name,h,w", [("enc_64x64", 64, 64), ("enc_128x192", 128, 192), ("enc_512x512", 512, 512)])
+def test_encoder_matches_golden_latents(vae, name, h, w):
+    g = golden("encoder_" + name)
+    x = synth.synth_images(1, h, w, seed=3)
+    lat = vae.encode(x.cuda()).cpu()
+    assert lat.shape == g["latent"].shape
+    err = (lat - g["latent"]).abs().max().item()
+    assert err <= TOL_LATENT_BF16, f"max |dlatent| = {err}"
+
+
+@pytest.mark.parametrize("h,w", [(72, 88), (100, 76)])
+def test_encoder_matches_oracle_on_odd_shapes(vae, h, w):
+    """non-multiple-of-64 (and non-multiple-of-8) inputs: ragged tiles, odd downsample sizes, S % 8 != 0."""
+    sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    x = synth.synth_images(2, h, w, seed=11)
+    ref = encoder_ref.vae_wrapper_encode(sd, x)
+    lat = vae.encode(x.cuda()).cpu()
+    assert lat.shape == ref.shape == (2, 16, h // 8, w // 8)
+    assert (lat - ref).abs().max().item() <= TOL_LATENT_BF16
+    # against the oracle with bf16 rounding at the same points the error is kernel noise only
+    emu = encoder_ref.vae_wrapper_encode(sd, x, emulate_bf16=True)
+    assert (lat - emu).abs().max().item() <= 6e-3
+
+
+def test_autoencoderkl_surface_moments_mode_sample(vae):
+    x = synth.synth_images(2, 64, 64, seed=5).cuda()
+    post = vae.vae.encode(x).latent_dist
+    assert post.parameters.shape == (2, 32, 8, 8)
+    scaled = vae.encode(x)
+    assert torch.allclose(post.mode() * 0.3611 + 0.1159, scaled, atol=1e-6)
+    assert post.sample().shape == (2, 16, 8, 8) and post.kl().shape == (2,)
+    sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    ref = encoder_ref.encoder_moments(sd, x.cpu())
+    assert (post.parameters.cpu() - ref).abs().max().item() <= 3e-2     # un-scaled moments: 1e-2 / 0.3611
+
+
+DEC = [("attn_n11_16x16", 11, (2, 16, 16, 16), (True, True, False)),
+       ("attn_n10000_64x64", 10000, (2, 16, 64, 64), (True, True, False)),
+       ("attn_n11_72x128", 11, (1, 16, 72, 128), (True, True, False)),
+       ("attn_cross_n11_16x16", 11, (2, 16, 16, 16), (True, True, True)),
+       ("attn_nospatial_n11_16x16", 11, (2, 16, 16, 16), (False, True, False))]
+
+
+@pytest.mark.parametrize("name,n,shape,flags", DEC)
+def test_decoder_matches_reference_outputs(name, n, shape, flags):
+    g = golden("decoder_" + name)
+    dec = _decoder(n, flags)
+    x = latent_input(shape, seed=7).cuda()
+    logits = dec(x).cpu()
+    err = (logits - g["logits"]).abs().max().item()
+    assert err <= TOL_LOGIT_F32, f"max |dlogit| = {err}"
+    conf, idx = dec.get_confidence(x)
+    conf, idx = conf.cpu(), idx.cpu()
+    assert torch.allclose(conf, g["conf_sorted"], atol=1e-5)
+    # bit-exact tag-index argsort wherever adjacent confidences differ by more than the fp32 tolerance
+    gap = (g["conf_sorted"][:, :-1] - g["conf_sorted"][:, 1:]).abs()
+    distinct = torch.ones_like(idx, dtype=torch.bool)
+    distinct[:, :-1] &= gap > 1e-5
+    distinct[:, 1:] &= gap > 1e-5
+    assert distinct.float().mean() > 0.5
+    assert torch.equal(idx[distinct], g["indices"][distinct])
+    # the device sort is exactly (logit desc, index asc) of the device logits
+    ref_conf, ref_idx = decoder_ref.get_confidence(logits)
+    assert torch.equal(idx, ref_idx)
+
+
+def test_plain_decoder_matches_reference_outputs():
+    g = golden("decoder_plain_n11_16x16")
+    dec = _decoder(11, plain=True)
+    logits = dec(latent_input((2, 16, 16, 16), seed=7).cuda()).cpu()
+    assert (logits - g["logits"]).abs().max().item() <= TOL_LOGIT_F32
+
+
+def test_sort_edge_cases():
+    dec = _decoder(11)
+    for n in (1, 2, 3, 1000, 16384):
+        lg = torch.randn(3, n, generator=torch.Generator().manual_seed(n))
+        lg[:, : n // 2] = lg[:, : n // 2].round()             # many exact ties
+        lg[0, 0] = 30.0                                       # sigmoid saturates to 1.0 here
+        conf, idx = dec.confidence_from_logits(lg.cuda())
+        rc, ri = decoder_ref.get_confidence(lg)
+        assert torch.equal(idx.cpu(), ri) and torch.allclose(conf.cpu(), rc, atol=1e-6)
+
+
+def test_encode_tag_pipeline_matches_oracle(vae):
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+    dec = _decoder(1000)
+    pipe = EncodeTagPipeline(vae, dec)
+    x = synth.synth_images(3, 128, 192, seed=21)
+    logits, lat = pipe.logits(x.cuda(), return_latent=True)
+    sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(1000), seed=1)
+    ref_lat = encoder_ref.vae_wrapper_encode(sd_e, x)
+    ref_logits = decoder_ref.attention_decoder_forward(sd_d, ref_lat)
+    assert (lat.cpu() - ref_lat).abs().max().item() <= TOL_LATENT_BF16
+    assert (logits.cpu() - ref_logits).abs().max().item() <= 1e-2       # north_star: logits within 1e-2
+    # same result through the two separate objects (reference call order, infer_full.py:101-102)
+    lat2 = vae.encode(x.cuda())
+    assert torch.equal(lat2, lat)
+    assert torch.equal(dec(lat2), logits)
+
+
+def test_full_size_properties(vae):
+    """BASELINE.json configs[1] size (1024^2): no CPU oracle at this size in test time, so check
+    size-independent properties: determinism, batch-permutation equivariance, batch-composition invariance."""
+    x = synth.synth_images(3, 1024, 1024, seed=31).cuda()
+    a = vae.encode(x)
+    b = vae.encode(x)
+    assert torch.equal(a, b), "non-deterministic"
+    assert torch.isfinite(a).all() and a.shape == (3, 16, 128, 128)
+    perm = torch.tensor([2, 0, 1], device="cuda")
+    assert torch.equal(vae.encode(x[perm]), a[perm])
+    assert torch.equal(vae.encode(x[1:2]), a[1:2])
+    # down-scaled copy of a 512^2 golden region is NOT expected to match; instead tie the big shape to the
+    # oracle through statistics the goldens recorded at 512^2 (same weights, same input distribution)
+    g = golden("encoder_enc_512x512")["latent"]
+    assert abs(a.mean().item() - g.mean().item()) < 0.02 and abs(a.std().item() - g.std().item()) < 0.02

@@ -1,0 +1,121 @@
+"""GPU parity, one kernel at a time, through the C ABI.  Oracle = torch CPU fp32 of the same op on
+the same bf16-rounded operands (a floating-point path: fp32 accumulate on both sides), so the
+tolerances below are accumulation-order noise, not bf16 slack."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import Ops, bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return Ops()
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return scale * torch.randn(shape, generator=g)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, stride, pad_lo, pad_hi
+    (2, 128, 128, 20, 24, 3, 1, 1, 1),      # ragged pixel tile, Cout=128 config
+    (1, 128, 256, 16, 16, 3, 1, 1, 1),      # 256x256 config
+    (1, 256, 512, 9, 13, 3, 1, 1, 1),       # odd sizes, two cout tiles
+    (2, 128, 128, 17, 22, 3, 2, 0, 1),      # Downsample2D: pad (0,1,0,1), stride 2, odd input
+    (1, 512, 512, 8, 8, 3, 2, 0, 1),
+    (1, 128, 256, 12, 20, 1, 1, 0, 0),      # conv_shortcut 1x1
+    (1, 512, 32, 16, 24, 3, 1, 1, 1),       # conv_out-shaped (Cout=32 config)
+    (3, 64, 64, 5, 7, 3, 1, 1, 1),          # Cin = one K chunk, tiny image
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,stride,plo,phi", CONV_CASES)
+def test_conv2d_matches_torch(ops, B, Cin, Cout, H, W, k, stride, plo, phi):
+    x = bf16_round(_rand((B, Cin, H, W), 1))
+    w = bf16_round(_rand((Cout, Cin, k, k), 2, (Cin * k * k) ** -0.5))
+    b = _rand((Cout,), 3, 0.1)
+    ref = F.conv2d(F.pad(x, (plo, phi, plo, phi)), w, b, stride=stride)
+    res = _rand(tuple(ref.shape), 4)
+    got32, got16 = ops.conv2d(x, w, b, residual_nchw=res, stride=stride, pad_lo=plo, pad_hi=phi, want="both")
+    ref = ref + res
+    assert got32.shape == ref.shape
+    assert torch.allclose(got32, ref, rtol=1e-4, atol=2e-4), (got32 - ref).abs().max()
+    assert torch.allclose(got16, bf16_round(ref), rtol=1e-2, atol=1e-2)
+    got = ops.conv2d(x, w, None, stride=stride, pad_lo=plo, pad_hi=phi)
+    assert torch.allclose(got, ref - res - b.view(1, -1, 1, 1), rtol=1e-4, atol=2e-4)
+
+
+def test_conv2d_identity_weights_asymmetric_input(ops):
+    """A = I style check with an asymmetric operand: catches a transposed C/D map or a swapped tap."""
+    Cin = Cout = 128
+    x = torch.arange(2 * Cin * 6 * 10, dtype=torch.float32).reshape(2, Cin, 6, 10) % 251 - 125.0
+    for tap in range(9):
+        w = torch.zeros(Cout, Cin, 3, 3)
+        w[torch.arange(Cout), torch.arange(Cin), tap // 3, tap % 3] = 1.0
+        ref = F.conv2d(x, w, padding=1)
+        got = ops.conv2d(x, w, None)
+        assert torch.equal(got, ref), f"tap {tap}"
+
+
+@pytest.mark.parametrize("batch,M,N,K", [(1, 300, 200, 512), (2, 64, 512, 128), (1, 257, 108, 72), (1, 100, 104, 1000)])
+def test_gemm_nt_matches_torch(ops, batch, M, N, K):
+    a = bf16_round(_rand((batch, M, K), 5))
+    b = bf16_round(_rand((batch, N, K), 6, K ** -0.5))
+    bias = _rand((N,), 7)
+    ref = torch.matmul(a, b.transpose(1, 2)) * 0.5 + bias
+    got = ops.gemm_nt(a, b, bias, alpha=0.5, lda=(K + 7) // 8 * 8 + 8, ldb=(K + 7) // 8 * 8)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=2e-4), (got - ref).abs().max()
+    rb = _rand((M,), 8)
+    got = ops.gemm_nt(a, b[:1], rb, bias_per_row=True, out_bf16=True, lda=(K + 7) // 8 * 8, ldb=(K + 7) // 8 * 8)
+    ref = torch.matmul(a, b[:1].transpose(1, 2)) + rb.view(1, M, 1)
+    assert torch.allclose(got, bf16_round(ref), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("C,H,W,in_bf16,silu", [(128, 40, 36, False, True), (256, 17, 9, False, True),
+                                                 (512, 16, 16, True, True), (512, 8, 8, False, False),
+                                                 (128, 64, 64, True, True), (64, 10, 10, False, True)])
+def test_groupnorm_silu_matches_torch(ops, C, H, W, in_bf16, silu):
+    x = _rand((2, C, H, W), 9) * 1.7 + 0.8
+    if in_bf16:
+        x = bf16_round(x)
+    g = 1 + 0.1 * _rand((C,), 10)
+    b = 0.1 * _rand((C,), 11)
+    ref = F.group_norm(x, 32, g, b, eps=1e-6)
+    if silu:
+        ref = F.silu(ref)
+    got = ops.groupnorm(x, g, b, silu=silu, in_bf16=in_bf16)
+    # output is bf16: half an ulp of bf16 (2^-9 relative) + stats noise
+    assert torch.allclose(got, ref, rtol=6e-3, atol=2e-3), (got - ref).abs().max()
+
+
+def test_groupnorm_large_mean_is_stable(ops):
+    x = _rand((1, 128, 32, 32), 12) * 0.05 + 30.0          # mean >> std: catastrophic for naive E[x^2]-E[x]^2 in fp32
+    g, b = torch.ones(128), torch.zeros(128)
+    ref = F.group_norm(x, 32, g, b, eps=1e-6)
+    got = ops.groupnorm(x, g, b, silu=False)
+    assert torch.allclose(got, ref, rtol=2e-2, atol=6e-2), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("H,W", [(16, 16), (33, 70), (7, 130)])
+def test_conv_in_matches_torch(ops, H, W):
+    x = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(13)) * 2 - 1
+    w = _rand((128, 3, 3, 3), 14, 27 ** -0.5)
+    b = _rand((128,), 15, 0.1)
+    ref = F.conv2d(x, w, b, padding=1)
+    got32, got16 = ops.conv_in(x, w, b)
+    assert torch.allclose(got32, ref, rtol=1e-5, atol=1e-5), (got32 - ref).abs().max()
+    assert torch.allclose(got16, bf16_round(ref), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("rows,n", [(5, 64), (3, 108), (2, 4096), (1, 16384)])
+def test_softmax_rows(ops, rows, n):
+    s = _rand((rows, n), 16) * 3
+    s[0, n // 2] = 40.0                                      # a spike: max-subtraction must hold
+    ref = torch.softmax(s, dim=-1)
+    got = ops.softmax_rows(s)
+    assert got.shape[1] % 8 == 0 and torch.all(got[:, n:] == 0)
+    assert torch.allclose(got[:, :n], ref, rtol=1e-2, atol=1e-6)

@@ -1,0 +1,116 @@
+"""CPU: host logic and the C-ABI surface (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from vae_tagger_amd import _lib, sharding, synth
+from vae_tagger_amd.modules import AspectRatioBucketing, get_vae_latent_info
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vae_tagger_hip.h")).read()
+    declared = set(re.findall(r"\b(vt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert b"gfx950" in _lib.load().vt_version()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libvae_tagger_hip.so")
+    with pytest.raises(_lib.VTError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_models_refuse_to_run_on_cpu():
+    from vae_tagger_amd.diffusers_vae_loader import DiffusersVAEWrapper, get_diffusers_vae_config, load_diffusers_vae_from_config
+    cfg = dict(get_diffusers_vae_config(), block_out_channels=[64, 64], down_block_types=["DownEncoderBlock2D"] * 2)
+    vae = DiffusersVAEWrapper(load_diffusers_vae_from_config(cfg))
+    with pytest.raises(_lib.VTError, match="no CPU fallback"):
+        vae.encode(torch.zeros(1, 3, 32, 32))
+
+
+def test_state_dict_surface_matches_reference_keys():
+    from vae_tagger_amd.autoencoder_kl import AutoencoderKL
+    from vae_tagger_amd.modules import create_attention_decoder
+    vae = AutoencoderKL(block_out_channels=(128, 256, 512, 512), latent_channels=16, use_quant_conv=False,
+                        scaling_factor=0.3611, shift_factor=0.1159)
+    assert set(vae.state_dict()) == set(synth.encoder_manifest())
+    assert sum(p.numel() for p in vae.parameters()) == 34_274_208
+    sd = synth.synth_state_dict(synth.encoder_manifest(), seed=5)
+    sd["decoder.conv_in.weight"] = torch.zeros(1)           # real checkpoints carry decoder.* too
+    del sd["encoder.conv_out.bias"]
+    missing, unexpected = vae.load_state_dict(sd, strict=False)
+    assert missing == ["encoder.conv_out.bias"] and unexpected == ["decoder.conv_in.weight"]
+    assert hasattr(vae.config, "scaling_factor") and hasattr(vae.config, "shift_factor")
+    dec = create_attention_decoder(16, 128, 128, 11, {"use_spatial_attention": True, "use_self_attention": True})
+    assert set(dec.state_dict()) == set(synth.attention_decoder_manifest(11))
+    assert sum(p.numel() for p in dec.parameters()) == 1_189_493
+
+
+def test_bucketing_matches_survey():
+    b = AspectRatioBucketing(512, 1024, 64)
+    assert len(b.buckets) == 81
+    assert b.bucket_for_ratio(1.0) == (512, 512)              # ties go to the smallest bucket
+    reach = {b.bucket_for_ratio(w / h) for w in range(256, 2049, 8) for h in range(256, 2049, 8)}
+    assert all(w % 64 == 0 and h % 64 == 0 for w, h in reach)
+    assert get_vae_latent_info(1024)["latent_height"] == 128
+
+
+def test_shard_range_and_cost_model():
+    for n in (1, 7, 16, 129):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert abs(sharding.image_cost(1024, 1024) - 4.8826) < 1e-3
+    assert abs(sharding.image_cost(512, 512) - 1.1176) < 2e-3
+    batches = [(1024, 1024, 8), (512, 512, 8), (960, 1024, 8), (512, 768, 8), (768, 512, 8), (640, 640, 8)]
+    assign, loads = sharding.assign_batches(batches, 4)
+    assert sorted(i for a in assign for i in a) == list(range(len(batches)))
+    assert max(loads) <= 1.05 * max(sharding.image_cost(w, h) * n for w, h, n in batches)
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from vae_tagger_amd import sharding
+from oracle import decoder_ref
+from vae_tagger_amd import synth
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+sd = synth.synth_state_dict(synth.attention_decoder_manifest(11), seed=1)
+g = torch.Generator().manual_seed(0)
+lat = torch.randn(5, 16, 16, 16, generator=g)            # 5 images over 2 ranks: ragged 3 + 2
+full = decoder_ref.attention_decoder_forward(sd, lat)
+out = sharding.sharded_logits(lambda x: decoder_ref.attention_decoder_forward(sd, x), lat)
+assert out.shape == full.shape and torch.allclose(out, full, atol=1e-6), (out - full).abs().max()
+lat4 = lat[:4]                                           # even split: single all-gather path
+out4 = sharding.sharded_logits(lambda x: decoder_ref.attention_decoder_forward(sd, x), lat4)
+assert torch.allclose(out4, full[:4], atol=1e-6)
+dist.barrier(); dist.destroy_process_group()
+print("rank", sys.argv[3], "ok")
+'''
+
+
+def test_sharded_logits_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

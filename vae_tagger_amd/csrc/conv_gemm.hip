@@ -1,0 +1,254 @@
+// Implicit-GEMM convolution / batched NT-GEMM on CDNA4 matrix cores (gfx950).
+//
+// One kernel serves every contraction on the encoder path:
+//   3x3 stride-1 pad-1 convs, 3x3 stride-2 convs with the asymmetric (0,1,0,1) pad, 1x1 shortcut
+//   convs, the attention projections, Q.K^T and P.V.  All are  out[p][c] = sum_k X[p,k] * W[c,k]
+//   with X rows gathered on the fly (im2col never materialised):
+//     k = (tap, ci);  X[p,(tap,ci)] = x[b, oy*stride-pad+ky, ox*stride-pad+kx, ci]  (0 outside)
+//
+// Layout: activations NHWC bf16 (channels contiguous => one 16-B lane load = 8 k-values of one
+// pixel), weights [Cout][tap][Cin] bf16 (k contiguous per cout).  Both operands therefore have
+// the "8 contiguous k per lane" shape v_mfma_f32_16x16x32_bf16 wants, for A and for B.
+//
+// MFMA orientation: weights are the A operand (rows = cout), pixels the B operand (cols = pixel),
+// so a lane's 4 accumulator registers are 4 CONSECUTIVE couts of ONE pixel -> 8-B/16-B vector
+// stores into NHWC rows, float4 residual loads, and GroupNorm partial sums that stay in-lane.
+//
+// Staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4): one wave-instruction writes 8 rows
+// x 128 B (BK = 64 bf16).  The DMA destination is lane-linear, so the bank-conflict swizzle
+// (16-B chunk ^ (row & 7)) is applied to the per-lane SOURCE address and again on the ds_read
+// side (guide rule 21).  Zero padding / tails: the lane's source points at a zero page.
+// Two LDS stages; one barrier per K-step; the next K-step's DMA is issued right after the barrier
+// and lands under the current step's MFMAs.
+#include "vt_common.h"
+#include "vt_kernels.h"
+
+namespace {
+
+constexpr int BK = 64;            // k-values per K-step (128-B LDS rows)
+constexpr int ROWB = BK * 2;      // bytes per LDS row
+
+template <int BP, int BC, int WP, int WC>
+__global__ __launch_bounds__(512) void conv_gemm_kernel(const ConvGemmArgs a) {
+    static_assert(WP * WC == 8, "8 waves per workgroup");
+    constexpr int TP = BP / WP / 16;          // 16-pixel MFMA tiles per wave
+    constexpr int TC = BC / WC / 16;          // 16-cout MFMA tiles per wave
+    constexpr int XI = BP / 8;                // DMA wave-instructions per X tile (8 rows each)
+    constexpr int WI = BC / 8;
+    constexpr int NXJ = (XI + 7) / 8;         // per wave
+    constexpr int NWJ = (WI + 7) / 8;
+    constexpr int STAGE_BYTES = (BP + BC) * ROWB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wp = wave / WC, wc = wave % WC;
+
+    // ---- tile coordinates (XCD-aware: cout tiles of one pixel tile + neighbours share an L2)
+    const int HWo = a.Hout * a.Wout;
+    const int ptiles = (HWo + BP - 1) / BP;
+    const int ctiles = (a.Cout + BC - 1) / BC;
+    const int per_img = ptiles * ctiles;
+    int logical = vt_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = logical / per_img;
+    logical -= b * per_img;
+    const int p0 = (logical / ctiles) * BP;
+    const int c0 = (logical % ctiles) * BC;
+
+    const bf16_t* Xb = a.X + (long long)b * a.x_bs;
+    const bf16_t* Wb = a.W + (long long)b * a.w_bs;
+
+    // ---- per-lane DMA bookkeeping.  Lane l of a wave-instruction writes LDS row (l>>3), physical
+    // chunk (l&7); the logical chunk it must fetch is (l&7) ^ (row&7) = (l&7) ^ (l>>3).
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+    const int ntaps = a.ksize * a.ksize;
+    const int ncb = (a.Cin + BK - 1) / BK;
+    const bool chunk_tail_possible = (a.Cin % BK) != 0;
+
+    int xoff[NXJ];          // element offset of (pixel's window origin, chunk) inside the image
+    unsigned xmask[NXJ];    // bit t set <=> tap t of this row is inside the image
+#pragma unroll
+    for (int j = 0; j < NXJ; ++j) {
+        const int r = (j * 8 + wave) * 8 + lrow;
+        const int p = p0 + r;
+        const bool rv = (r < BP) && (p < HWo);
+        const int oy = p / a.Wout, ox = p - oy * a.Wout;
+        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        xoff[j] = (iy0 * a.Win + ix0) * a.ldx + lchunk * 8;
+        unsigned m = 0;
+        if (rv) {
+            for (int t = 0; t < ntaps; ++t) {
+                const int ky = t / a.ksize, kx = t - ky * a.ksize;
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) m |= 1u << t;
+            }
+        }
+        xmask[j] = m;
+    }
+    int woff[NWJ];
+    bool wvalid[NWJ];
+#pragma unroll
+    for (int j = 0; j < NWJ; ++j) {
+        const int rblk = j * 8 + wave;
+        const int n = c0 + rblk * 8 + lrow;
+        wvalid[j] = (rblk < WI) && (n < a.Wrows);
+        woff[j] = n * a.ldw + lchunk * 8;
+    }
+
+    auto stage = [&](int tap, int cb, int buf) {
+        char* xs = smem + buf * STAGE_BYTES;
+        char* ws = xs + BP * ROWB;
+        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;      // tap < 9
+        const int doff = (a.ksize == 1) ? 0 : (ky * a.Win + kx) * a.ldx;
+        const int k0 = cb * BK;
+        const bool cv = !chunk_tail_possible || (k0 + lchunk * 8 < a.Cin);
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) {
+            const int rblk = j * 8 + wave;
+            if (XI % 8 == 0 || rblk < XI) {
+                const bool v = ((xmask[j] >> tap) & 1u) && cv;
+                const void* src = v ? (const void*)(Xb + (xoff[j] + doff + k0)) : a.zeros;
+                __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(xs + rblk * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NWJ; ++j) {
+            const int rblk = j * 8 + wave;
+            if (WI % 8 == 0 || rblk < WI) {
+                const bool v = wvalid[j] && cv;
+                const void* src = v ? (const void*)(Wb + (woff[j] + tap * a.Cin + k0)) : a.zeros;
+                __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(ws + rblk * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment read offsets: lane reads row (tile_base + (lane&15)), logical chunk kk*4+(lane>>4),
+    // stored at physical chunk ^ (row&7) = ^ (lane&7) (tile bases are multiples of 16).
+    const int frow = lane & 15;
+    const int fq = lane >> 4;
+    const int foff0 = frow * ROWB + (((0 + fq) ^ (lane & 7)) << 4);
+    const int foff1 = frow * ROWB + (((4 + fq) ^ (lane & 7)) << 4);
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = ntaps * ncb;
+    stage(0, 0, 0);
+    int tap_n = 0, cb_n = 1;                 // coordinates of the NEXT K-step to stage
+    if (cb_n == ncb) { cb_n = 0; tap_n = 1; }
+
+    for (int t = 0; t < nk; ++t) {
+        __syncthreads();                     // vmcnt(0) + barrier: tile t landed, buffer (t+1)&1 free
+        if (t + 1 < nk) {
+            stage(tap_n, cb_n, (t + 1) & 1);
+            if (++cb_n == ncb) { cb_n = 0; ++tap_n; }
+        }
+        const char* xs = smem + (t & 1) * STAGE_BYTES + (wp * (BP / WP)) * ROWB;
+        const char* ws = smem + (t & 1) * STAGE_BYTES + BP * ROWB + (wc * (BC / WC)) * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int fo = kk ? foff1 : foff0;
+            bf16x8 wf[TC], xf[TP];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wf[i] = *(const bf16x8*)(ws + i * 16 * ROWB + fo);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) xf[j] = *(const bf16x8*)(xs + j * 16 * ROWB + fo);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds couts cg..cg+3 (regs) of pixel p for every (i, j) tile.
+    const long long ob = (long long)b * a.o_bs;
+    const float* resb = a.res ? a.res + (long long)b * a.r_bs : nullptr;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int p = p0 + wp * (BP / WP) + j * 16 + frow;
+        if (p >= HWo) continue;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int cg = c0 + wc * (BC / WC) + i * 16 + fq * 4;
+            if (cg >= a.Cout) continue;
+            f32x4 v = acc[i][j] * a.alpha;
+            if (a.bias_mode == 1) {
+                const f32x4 bv = *(const f32x4*)(a.bias + cg);
+                v += bv;
+            } else if (a.bias_mode == 2) {
+                const float bv = a.bias[p];
+                v += f32x4{bv, bv, bv, bv};
+            }
+            if (a.out_mode == 1) {
+                // latent: fp32 NCHW, first cout_keep channels, affine post-scale (DiffusersVAEWrapper.encode)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (cg + r < a.cout_keep)
+                        a.out_f32[ob + (long long)(cg + r) * HWo + p] = v[r] * a.post_scale + a.post_shift;
+                continue;
+            }
+            const long long o = (long long)p * a.ldo + cg;
+            if (resb) {
+                const f32x4 rv = *(const f32x4*)(resb + (long long)p * a.ldr + cg);
+                v += rv;
+            }
+            if (a.out_f32) *(f32x4*)(a.out_f32 + ob + o) = v;
+            if (a.out_bf16) {
+                bf16x4 h;
+                h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
+                *(bf16x4*)(a.out_bf16 + ob + o) = h;
+            }
+        }
+    }
+}
+
+template <int BP, int BC, int WP, int WC>
+hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
+    constexpr int smem = 2 * (BP + BC) * ROWB;
+    static bool attr_set = false;
+    auto kern = conv_gemm_kernel<BP, BC, WP, WC>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int HWo = a.Hout * a.Wout;
+    const int ptiles = (HWo + BP - 1) / BP, ctiles = (a.Cout + BC - 1) / BC;
+    const long long nblk = (long long)ptiles * ctiles * a.batch;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), smem, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// Host-side shape validation lives here so a bad call can never reach the DMA address math.
+hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
+    if (!a.X || !a.W || !a.zeros) return hipErrorInvalidValue;
+    if (a.ksize != 1 && a.ksize != 3) return hipErrorInvalidValue;
+    if (a.Cin <= 0 || a.Cout <= 0 || a.batch <= 0 || a.Wrows <= 0 || a.Wrows > a.Cout) return hipErrorInvalidValue;
+    if ((a.ldx % 8) || (a.ldw % 8)) return hipErrorInvalidValue;          // 16-B aligned rows for the DMA
+    if (a.out_mode == 0 && ((a.ldo % 4) || (a.Cout % 4))) return hipErrorInvalidValue;
+    if (a.res && (a.ldr % 4)) return hipErrorInvalidValue;
+    if (a.Cin % 8) return hipErrorInvalidValue;                           // k tail handled per 8-element chunk
+    // per-image offsets are 32-bit
+    if ((long long)a.Hin * a.Win * a.ldx >= (1LL << 31)) return hipErrorInvalidValue;
+    if ((long long)a.Wrows * a.ldw >= (1LL << 31)) return hipErrorInvalidValue;
+    switch (vt_conv_gemm_config(a)) {
+        case 0: return launch_cfg<128, 32, 8, 1>(a, s);
+        case 1: return launch_cfg<256, 128, 4, 2>(a, s);
+        default: return launch_cfg<256, 256, 2, 4>(a, s);
+    }
+}
+
+int vt_conv_gemm_config(const ConvGemmArgs& a) { return a.Cout <= 32 ? 0 : (a.Cout <= 128 ? 1 : 2); }
+const char* vt_conv_gemm_config_name(int cfg) {
+    static const char* n[3] = {"conv_gemm_kernel<128,32,8,1>", "conv_gemm_kernel<256,128,4,2>", "conv_gemm_kernel<256,256,2,4>"};
+    return (cfg >= 0 && cfg < 3) ? n[cfg] : "?";
+}

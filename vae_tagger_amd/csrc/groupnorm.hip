@@ -1,0 +1,212 @@
+// GroupNorm(32, eps) + optional SiLU on NHWC rows -- the HBM-bound half of the encoder
+// (SURVEY.md section 2, K4).  Three launches:
+//   stats    : one read of x  -> per (image, pixel-chunk, group) partial (sum, sumsq), fp32
+//   finalize : deterministic fixed-order merge in fp64 -> per (image, channel) (scale, shift)
+//   apply    : y = act(x*scale + shift), one read of x, one bf16 write (the MFMA operand of the next conv)
+// x is the fp32 residual stream or a bf16 conv output.  16-B vector accesses, 8 channels per lane.
+#include "vt_common.h"
+#include "vt_kernels.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_CHUNK_PIX = 1024;     // pixels per stats block (upper bound)
+
+template <typename T> struct Load8;
+template <> struct Load8<float> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+};
+template <> struct Load8<bf16_t> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+        const bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
+};
+
+// SLOTS = groups covered by one lane's 8 channels = max(1, 8 / channels_per_group)
+template <typename T, int SLOTS>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int cpg,
+                                                              int chunk_pix, int nchunks,
+                                                              float* __restrict__ partial) {
+    __shared__ float red[GN_THREADS][SLOTS][2];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int tpp = C >> 3;                       // lanes per pixel
+    const int ppp = GN_THREADS / tpp;             // pixels per pass
+    const int tc = threadIdx.x % tpp;             // this lane's channel chunk (fixed for the whole block)
+    const int tp = threadIdx.x / tpp;
+    const int pbeg = chunk * chunk_pix;
+    const int pend = min(HW, pbeg + chunk_pix);
+    const T* xb = x + ((long long)b * HW) * C + tc * 8;
+    float s[SLOTS], ss[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) s[i] = ss[i] = 0.f;
+    constexpr int PER = 8 / SLOTS;
+#pragma unroll 4
+    for (int p = pbeg + tp; p < pend; p += ppp) {
+        float v[8];
+        Load8<T>::ld(xb + (long long)p * C, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s[i / PER] += v[i];
+            ss[i / PER] = fmaf(v[i], v[i], ss[i / PER]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) { red[threadIdx.x][i][0] = s[i]; red[threadIdx.x][i][1] = ss[i]; }
+    __syncthreads();
+    // one lane per group sums its contributors in a fixed order (deterministic)
+    const int groups = C / cpg;
+    if ((int)threadIdx.x < groups) {
+        const int g = threadIdx.x;
+        float a0 = 0.f, a1 = 0.f;
+        if (SLOTS > 1) {
+            const int ct = (g * cpg) >> 3, sl = ((g * cpg) & 7) / cpg;   // lane-chunk and slot holding group g
+            for (int q = 0; q < ppp; ++q) { a0 += red[q * tpp + ct][sl][0]; a1 += red[q * tpp + ct][sl][1]; }
+        } else {
+            const int nct = cpg >> 3, ct0 = (g * cpg) >> 3;              // group spans nct lane-chunks
+            for (int q = 0; q < ppp; ++q)
+                for (int c = 0; c < nct; ++c) { a0 += red[q * tpp + ct0 + c][0][0]; a1 += red[q * tpp + ct0 + c][0][1]; }
+        }
+        float* o = partial + (((long long)b * nchunks + chunk) * groups + g) * 2;
+        o[0] = a0; o[1] = a1;
+    }
+}
+
+// one wave per (image, group): fixed lane<-chunk assignment, fp64 merge, xor-shuffle tree => deterministic
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int HW,
+                                                         int C, int groups, int chunk_pix, float eps,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         float* __restrict__ scale_shift) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int cpg = C / groups;
+    const float* pb = partial + ((long long)b * nchunks * groups + g) * 2;
+    double s = 0.0;
+    for (int c = lane; c < nchunks; c += 64) s += (double)pb[(long long)c * groups * 2];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    // M2 = sum_c [ ss_c - 2*mean*s_c + n_c*mean^2 ]  (each term small and positive-ish; fp64)
+    double m2 = 0.0;
+    for (int c = lane; c < nchunks; c += 64) {
+        const double sc = pb[(long long)c * groups * 2], ssc = pb[(long long)c * groups * 2 + 1];
+        const int pix = min(chunk_pix, HW - c * chunk_pix);
+        const double nc = (double)pix * cpg;
+        m2 += ssc - 2.0 * mean * sc + nc * mean * mean;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+    double var = m2 / n;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    for (int c = lane; c < cpg; c += 64) {
+        const int ch = g * cpg + c;
+        const float sc = rstd * gamma[ch];
+        float* o = scale_shift + ((long long)b * C + ch) * 2;
+        o[0] = sc;
+        o[1] = beta[ch] - fmean * sc;
+    }
+}
+
+template <typename T, bool SILU>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x,
+                                                              const float* __restrict__ scale_shift,
+                                                              bf16_t* __restrict__ y, int HW, int C,
+                                                              int pix_per_block) {
+    const int b = blockIdx.y;
+    const int tpp = C >> 3, ppp = GN_THREADS / tpp;
+    const int tc = threadIdx.x % tpp, tp = threadIdx.x / tpp;
+    float sc[8], sh[8];
+    const float* ssb = scale_shift + ((long long)b * C + tc * 8) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 q = *(const f32x4*)(ssb + i * 4);
+        sc[2 * i] = q[0]; sh[2 * i] = q[1]; sc[2 * i + 1] = q[2]; sh[2 * i + 1] = q[3];
+    }
+    const int pbeg = blockIdx.x * pix_per_block;
+    const int pend = min(HW, pbeg + pix_per_block);
+    const long long base = ((long long)b * HW) * C + tc * 8;
+#pragma unroll 4
+    for (int p = pbeg + tp; p < pend; p += ppp) {
+        float v[8];
+        Load8<T>::ld(x + base + (long long)p * C, v);
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = fmaf(v[i], sc[i], sh[i]);
+            if (SILU) t = vt_silu(t);
+            o[i] = (bf16_t)t;
+        }
+        *(bf16x8*)(y + base + (long long)p * C) = o;
+    }
+}
+
+bool gn_shape_ok(int C, int groups) {
+    if (C <= 0 || groups <= 0 || C % groups) return false;
+    const int cpg = C / groups;
+    if (C % 8 || (GN_THREADS % (C / 8)) != 0 || C / 8 > GN_THREADS) return false;
+    if (cpg & (cpg - 1)) return false;         // power of two
+    if (cpg < 2) return false;
+    return true;
+}
+
+int chunk_pix_for(int HW, int C) {
+    const int ppp = GN_THREADS / (C / 8);
+    int cp = GN_CHUNK_PIX;
+    if (cp < ppp) cp = ppp;
+    return cp;
+}
+
+}  // namespace
+
+int vt_gn_max_chunks(int HW, int C) {
+    const int cp = chunk_pix_for(HW, C);
+    return (HW + cp - 1) / cp;
+}
+
+hipError_t vt_launch_gn_stats(const void* x, int x_is_f32, int B, int HW, int C, int groups, float* partial,
+                              int* nchunks_out, hipStream_t s) {
+    if (!gn_shape_ok(C, groups) || B <= 0 || HW <= 0) return hipErrorInvalidValue;
+    const int cpg = C / groups;
+    const int cp = chunk_pix_for(HW, C);
+    const int nchunks = (HW + cp - 1) / cp;
+    if (nchunks_out) *nchunks_out = nchunks;
+    dim3 grid(nchunks, B), block(GN_THREADS);
+    const int slots = cpg >= 8 ? 1 : 8 / cpg;
+#define GN_STATS(T, S) hipLaunchKernelGGL((gn_stats_kernel<T, S>), grid, block, 0, s, (const T*)x, HW, C, cpg, cp, nchunks, partial)
+    if (x_is_f32) {
+        if (slots == 1) GN_STATS(float, 1); else if (slots == 2) GN_STATS(float, 2); else GN_STATS(float, 4);
+    } else {
+        if (slots == 1) GN_STATS(bf16_t, 1); else if (slots == 2) GN_STATS(bf16_t, 2); else GN_STATS(bf16_t, 4);
+    }
+#undef GN_STATS
+    return hipGetLastError();
+}
+
+hipError_t vt_launch_gn_finalize(const float* partial, int nchunks, int B, int HW, int C, int groups, float eps,
+                                 const float* gamma, const float* beta, float* scale_shift, hipStream_t s) {
+    if (!gn_shape_ok(C, groups)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, s, partial, nchunks, HW, C, groups,
+                       chunk_pix_for(HW, C), eps, gamma, beta, scale_shift);
+    return hipGetLastError();
+}
+
+hipError_t vt_launch_gn_apply(const void* x, int x_is_f32, const float* scale_shift, bf16_t* y, int B, int HW,
+                              int C, int silu, hipStream_t s) {
+    if (C % 8 || (GN_THREADS % (C / 8)) != 0 || C / 8 > GN_THREADS || B <= 0 || HW <= 0) return hipErrorInvalidValue;
+    const int ppp = GN_THREADS / (C / 8);
+    int ppb = 256;                                   // pixels per block
+    if (ppb < ppp) ppb = ppp;
+    dim3 grid((HW + ppb - 1) / ppb, B), block(GN_THREADS);
+#define GN_APPLY(T, A) hipLaunchKernelGGL((gn_apply_kernel<T, A>), grid, block, 0, s, (const T*)x, scale_shift, y, HW, C, ppb)
+    if (x_is_f32) { if (silu) GN_APPLY(float, true); else GN_APPLY(float, false); }
+    else { if (silu) GN_APPLY(bf16_t, true); else GN_APPLY(bf16_t, false); }
+#undef GN_APPLY
+    return hipGetLastError();
+}

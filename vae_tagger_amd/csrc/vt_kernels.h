@@ -1,0 +1,56 @@
+// Internal launcher interface between the kernel translation units and the C-ABI (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vt_common.h"
+
+struct ConvGemmArgs {
+    const bf16_t* X;        // activations NHWC bf16 / generic row-major A operand
+    const bf16_t* W;        // [Cout][taps][Cin] bf16 (k contiguous) / generic row-major B^T operand
+    const float* bias;      // fp32, per cout (mode 1) or per pixel-row (mode 2)
+    const float* res;       // optional fp32 residual, indexed like the output rows
+    float* out_f32;         // optional fp32 output rows [p][ldo]
+    bf16_t* out_bf16;       // optional bf16 output rows [p][ldo]
+    const void* zeros;      // >= 16 zero bytes in device memory (padding / tail source for the DMA)
+    float* gn_partial;      // optional [batch][ptiles][32][2] (sum, sumsq) of the stored values
+    int Hin, Win, Hout, Wout;
+    int Cin, Cout;             // k per tap; output columns written
+    int Wrows;                 // rows of W that exist (rows >= Wrows read as zero)
+    int ksize, stride, pad;
+    int ldx, ldw, ldo, ldr;         // row strides in elements
+    long long x_bs, w_bs, o_bs, r_bs;  // batch strides in elements
+    int batch;
+    float alpha;
+    int bias_mode;          // 0 none, 1 per cout, 2 per pixel-row
+    int out_mode;           // 0 rows, 1 latent NCHW fp32 (first cout_keep channels, * post_scale + post_shift)
+    int cout_keep;
+    float post_scale, post_shift;
+    int gn_cpg;             // channels per group for gn_partial (0 = off)
+};
+
+hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s);
+// which tile configuration the dispatcher picks for these args: 0 = 128x32, 1 = 256x128, 2 = 256x256
+int vt_conv_gemm_config(const ConvGemmArgs& a);
+const char* vt_conv_gemm_config_name(int cfg);
+
+// conv_in: fp32 NCHW image -> NHWC 128-channel fp32 (+ optional bf16) rows, direct fp32 conv 3x3 p1.
+hipError_t vt_launch_conv_in(const float* x_nchw, const float* w_packed /*[27][Cout]*/, const float* bias,
+                             float* out_f32, bf16_t* out_bf16, int B, int H, int W, int Cout, hipStream_t s);
+
+// GroupNorm statistics: x rows [B][HW][C] (fp32 or bf16) -> partial (count, mean, M2) per
+// (b, chunk, group), then finalize -> per (b, c) scale/shift so that y = x*scale + shift.
+hipError_t vt_launch_gn_stats(const void* x, int x_is_f32, int B, int HW, int C, int groups,
+                              float* partial, int* nchunks_out, hipStream_t s);
+hipError_t vt_launch_gn_finalize(const float* partial, int nchunks, int B, int HW, int C, int groups, float eps,
+                                 const float* gamma, const float* beta, float* scale_shift /*[B][C][2]*/,
+                                 hipStream_t s);
+int vt_gn_max_chunks(int HW, int C);
+// y = act(x*scale + shift) -> bf16 rows
+hipError_t vt_launch_gn_apply(const void* x, int x_is_f32, const float* scale_shift, bf16_t* y, int B, int HW,
+                              int C, int silu, hipStream_t s);
+
+// row softmax: scores fp32 [rows][lds] -> probs bf16 [rows][ldp]; columns [n, ldp) are written as zero.
+hipError_t vt_launch_softmax_rows(const float* scores, bf16_t* probs, int rows, int n, int lds, int ldp,
+                                  hipStream_t s);
+
+// decoder (all fp32)
+struct DecoderWeights;   // defined in capi.hip

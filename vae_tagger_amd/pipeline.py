@@ -1,0 +1,66 @@
+"""Batched encode+tag pipeline: the loop body of infer_full.py:95-105 for a whole batch, one
+vt_context holding both models, one C call per batch (vt_encode_tag), plus the data-parallel
+sharding of SURVEY.md section 8e (images are independent; the only exchange is an all-gather of logits).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._runtime import as_input, stream_ptr, vp, workspace
+from .autoencoder_kl import AutoencoderKL
+from .diffusers_vae_loader import DiffusersVAEWrapper
+from .modules import _HipDecoder
+
+
+class EncodeTagPipeline:
+    def __init__(self, vae_model, decoder, device=None):
+        vae = vae_model.vae if isinstance(vae_model, DiffusersVAEWrapper) else vae_model
+        if not isinstance(vae, AutoencoderKL) or not isinstance(decoder, _HipDecoder):
+            raise TypeError("EncodeTagPipeline needs vae_tagger_amd's AutoencoderKL (or its wrapper) and decoder")
+        self.vae, self.decoder = vae, decoder
+        dev = next(vae.parameters()).device if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.VTError("EncodeTagPipeline runs on a HIP device only; move the models with .to('cuda')")
+        self.device = dev
+        self.ctx = _lib.Context(dev.index if dev.index is not None else torch.cuda.current_device())
+        vae._upload(self.ctx)
+        decoder._upload(self.ctx)
+        self.num_classes = decoder.num_classes
+        self.latent_channels = vae.config.latent_channels
+        self._nd = len(vae.config.block_out_channels) - 1
+
+    def flops_per_image(self, H, W):
+        return self.ctx.lib.vt_encoder_flops(self.ctx.handle, H, W)
+
+    @torch.no_grad()
+    def logits(self, x, return_latent=False):
+        """x fp32 [B,3,H,W] on the device -> logits fp32 [B,N] (and the scaled latent if asked)."""
+        x = as_input(x)
+        if x.device != self.device:
+            x = x.to(self.device)
+        B, _, H, W = x.shape
+        out = torch.empty(B, self.num_classes, dtype=torch.float32, device=self.device)
+        lat = None
+        if return_latent:
+            lat = torch.empty(B, self.latent_channels, H >> self._nd, W >> self._nd, dtype=torch.float32,
+                              device=self.device)
+        need = self.ctx.lib.vt_encode_tag_workspace_bytes(self.ctx.handle, B, H, W)
+        if need == 0:
+            raise _lib.VTError(f"unsupported batch shape {tuple(x.shape)}")
+        ws, ptr = workspace(self.device, need)
+        self.ctx.call("vt_encode_tag", vp(x), B, H, W, vp(lat), vp(out), ctypes.c_void_p(ptr), need,
+                      stream_ptr(self.device))
+        return (out, lat) if return_latent else out
+
+    @torch.no_grad()
+    def confidence(self, logits):
+        logits = logits.contiguous()
+        B, N = logits.shape
+        conf = torch.empty_like(logits)
+        idx = torch.empty(B, N, dtype=torch.int64, device=logits.device)
+        self.ctx.call("vt_get_confidence", vp(logits), B, N, vp(conf), vp(idx), stream_ptr(logits.device))
+        return conf, idx
+
+    def tag(self, x):
+        return self.confidence(self.logits(x))
