@@ -30,8 +30,9 @@ def _bf16(t):
 
 
 class _Q:
-    """Rounding policy: identity (fp32 oracle) or bf16 at the points where the HIP path
-    stores / feeds bf16 (numerics study + tight kernel check; never the parity target)."""
+    """Rounding policy: identity (fp32 oracle) or bf16 at the points where the HIP path feeds bf16
+    to the matrix cores (weights, GroupNorm outputs, conv1 outputs, q/k/v/P/o); the residual stream
+    stays fp32 there too.  Numerics study only -- never the parity target."""
 
     def __init__(self, emulate_bf16):
         self.on = emulate_bf16
@@ -59,10 +60,10 @@ def _resnet(h, sd, p, q):
     t = _gn(t, sd, p + ".norm2", q, True)
     t = _conv(t, sd, p + ".conv2", q)
     if (p + ".conv_shortcut.weight") in sd:
-        s = _conv(h, sd, p + ".conv_shortcut", q, padding=0)
+        s = _conv(q(h), sd, p + ".conv_shortcut", q, padding=0)
     else:
         s = h
-    return q(t + s)
+    return t + s
 
 
 def _attention(h, sd, p, q):
@@ -79,7 +80,7 @@ def _attention(h, sd, p, q):
     o = q(torch.matmul(q(probs), vv))
     o = F.linear(o, q(sd[p + ".to_out.0.weight"]), sd[p + ".to_out.0.bias"])
     o = o.transpose(1, 2).reshape(b, c, hh, ww)
-    return q(o + h)
+    return o + h
 
 
 def encoder_moments(sd, x, emulate_bf16=False, n_down=4, layers_per_block=2, taps=None):
@@ -87,7 +88,7 @@ def encoder_moments(sd, x, emulate_bf16=False, n_down=4, layers_per_block=2, tap
     `taps`, if a dict, receives named intermediate activations."""
     q = _Q(emulate_bf16)
     sd = {k: v.to(torch.float32) for k, v in sd.items() if k.startswith("encoder.")}
-    h = q(_conv(q(x), sd, "encoder.conv_in", q))
+    h = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)   # fp32 on the HIP path too
     if taps is not None:
         taps["conv_in"] = h
     for i in range(n_down):
@@ -98,7 +99,7 @@ def encoder_moments(sd, x, emulate_bf16=False, n_down=4, layers_per_block=2, tap
         d = f"encoder.down_blocks.{i}.downsamplers.0.conv"
         if (d + ".weight") in sd:
             # diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) then conv stride 2
-            h = q(_conv(F.pad(h, (0, 1, 0, 1)), sd, d, q, stride=2, padding=0))
+            h = _conv(F.pad(q(h), (0, 1, 0, 1)), sd, d, q, stride=2, padding=0)
     h = _resnet(h, sd, "encoder.mid_block.resnets.0", q)
     h = _attention(h, sd, "encoder.mid_block.attentions.0", q)
     if taps is not None:

@@ -22,6 +22,7 @@ class ParamTree(nn.Module):
     def __init__(self, manifest, seed=0):
         super().__init__()
         self._manifest = dict(manifest)
+        synth._note_fan_in(self._manifest)
         for key, shape in self._manifest.items():
             parts = key.split(".")
             node = self

@@ -1,6 +1,6 @@
 // GroupNorm(32, eps) + optional SiLU on NHWC rows -- the HBM-bound half of the encoder
 // (SURVEY.md section 2, K4).  Three launches:
-//   stats    : one read of x  -> per (image, pixel-chunk, group) partial (sum, sumsq), fp32
+//   stats    : one read of x  -> per (image, pixel-chunk, group) partial (mean, M2), pivot-shifted fp32
 //   finalize : deterministic fixed-order merge in fp64 -> per (image, channel) (scale, shift)
 //   apply    : y = act(x*scale + shift), one read of x, one bf16 write (the MFMA operand of the next conv)
 // x is the fp32 residual stream or a bf16 conv output.  16-B vector accesses, 8 channels per lane.
@@ -27,12 +27,23 @@ template <> struct Load8<bf16_t> {
     }
 };
 
+// Numerically robust partials: every lane accumulates sums of (v - pivot), pivot = the first value it
+// sees for that slot, so E[d^2] - E[d]^2 never cancels even when |mean| >> std; lanes, chunks and
+// images are then merged as (n, mean, M2) triples with Chan's formula in a FIXED order (deterministic).
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    if (nb == 0.f) return;
+    const float nn = n + nb, d = mb - mean;
+    mean += d * (nb / nn);
+    m2 += m2b + d * d * (n * nb / nn);
+    n = nn;
+}
+
 // SLOTS = groups covered by one lane's 8 channels = max(1, 8 / channels_per_group)
 template <typename T, int SLOTS>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int cpg,
                                                               int chunk_pix, int nchunks,
                                                               float* __restrict__ partial) {
-    __shared__ float red[GN_THREADS][SLOTS][2];
+    __shared__ float red[GN_THREADS][SLOTS][3];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int tpp = C >> 3;                       // lanes per pixel
     const int ppp = GN_THREADS / tpp;             // pixels per pass
@@ -41,38 +52,53 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
     const int pbeg = chunk * chunk_pix;
     const int pend = min(HW, pbeg + chunk_pix);
     const T* xb = x + ((long long)b * HW) * C + tc * 8;
-    float s[SLOTS], ss[SLOTS];
-#pragma unroll
-    for (int i = 0; i < SLOTS; ++i) s[i] = ss[i] = 0.f;
     constexpr int PER = 8 / SLOTS;
+    float s[SLOTS], ss[SLOTS], piv[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) s[i] = ss[i] = piv[i] = 0.f;
+    int cnt = 0;
+    if (pbeg + tp < pend) {
+        float v[8];
+        Load8<T>::ld(xb + (long long)(pbeg + tp) * C, v);
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) piv[i] = v[i * PER];
+    }
 #pragma unroll 4
     for (int p = pbeg + tp; p < pend; p += ppp) {
         float v[8];
         Load8<T>::ld(xb + (long long)p * C, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            s[i / PER] += v[i];
-            ss[i / PER] = fmaf(v[i], v[i], ss[i / PER]);
+            const float d = v[i] - piv[i / PER];
+            s[i / PER] += d;
+            ss[i / PER] = fmaf(d, d, ss[i / PER]);
         }
+        ++cnt;
     }
+    const float nt = (float)(cnt * PER);
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) { red[threadIdx.x][i][0] = s[i]; red[threadIdx.x][i][1] = ss[i]; }
+    for (int i = 0; i < SLOTS; ++i) {
+        const float ms = cnt ? s[i] / nt : 0.f;
+        red[threadIdx.x][i][0] = nt;
+        red[threadIdx.x][i][1] = piv[i] + ms;
+        red[threadIdx.x][i][2] = cnt ? fmaxf(ss[i] - s[i] * ms, 0.f) : 0.f;
+    }
     __syncthreads();
-    // one lane per group sums its contributors in a fixed order (deterministic)
+    // one lane per group merges its contributors in a fixed order
     const int groups = C / cpg;
     if ((int)threadIdx.x < groups) {
         const int g = threadIdx.x;
-        float a0 = 0.f, a1 = 0.f;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
         if (SLOTS > 1) {
             const int ct = (g * cpg) >> 3, sl = ((g * cpg) & 7) / cpg;   // lane-chunk and slot holding group g
-            for (int q = 0; q < ppp; ++q) { a0 += red[q * tpp + ct][sl][0]; a1 += red[q * tpp + ct][sl][1]; }
+            for (int q = 0; q < ppp; ++q) chan_merge(n, mean, m2, red[q * tpp + ct][sl][0], red[q * tpp + ct][sl][1], red[q * tpp + ct][sl][2]);
         } else {
             const int nct = cpg >> 3, ct0 = (g * cpg) >> 3;              // group spans nct lane-chunks
             for (int q = 0; q < ppp; ++q)
-                for (int c = 0; c < nct; ++c) { a0 += red[q * tpp + ct0 + c][0][0]; a1 += red[q * tpp + ct0 + c][0][1]; }
+                for (int c = 0; c < nct; ++c) chan_merge(n, mean, m2, red[q * tpp + ct0 + c][0][0], red[q * tpp + ct0 + c][0][1], red[q * tpp + ct0 + c][0][2]);
         }
         float* o = partial + (((long long)b * nchunks + chunk) * groups + g) * 2;
-        o[0] = a0; o[1] = a1;
+        o[0] = mean; o[1] = m2;                   // the chunk's element count follows from its geometry
     }
 }
 
@@ -86,23 +112,23 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     const int cpg = C / groups;
     const float* pb = partial + ((long long)b * nchunks * groups + g) * 2;
     double s = 0.0;
-    for (int c = lane; c < nchunks; c += 64) s += (double)pb[(long long)c * groups * 2];
+    for (int c = lane; c < nchunks; c += 64) {
+        const int pix = min(chunk_pix, HW - c * chunk_pix);
+        s += (double)pix * cpg * (double)pb[(long long)c * groups * 2];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const double n = (double)HW * cpg;
     const double mean = s / n;
-    // M2 = sum_c [ ss_c - 2*mean*s_c + n_c*mean^2 ]  (each term small and positive-ish; fp64)
     double m2 = 0.0;
     for (int c = lane; c < nchunks; c += 64) {
-        const double sc = pb[(long long)c * groups * 2], ssc = pb[(long long)c * groups * 2 + 1];
+        const double mc = pb[(long long)c * groups * 2], m2c = pb[(long long)c * groups * 2 + 1];
         const int pix = min(chunk_pix, HW - c * chunk_pix);
-        const double nc = (double)pix * cpg;
-        m2 += ssc - 2.0 * mean * sc + nc * mean * mean;
+        m2 += m2c + (double)pix * cpg * (mc - mean) * (mc - mean);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
-    double var = m2 / n;
-    if (var < 0.0) var = 0.0;
+    const double var = m2 / n;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float fmean = (float)mean;
     for (int c = lane; c < cpg; c += 64) {

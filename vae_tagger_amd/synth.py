@@ -2,7 +2,8 @@
 
 There is no FLUX VAE checkpoint and no trained decoder in this environment, so
 benchmarks, smoke runs and parity fixtures use random-initialised weights of the
-reference architecture.  Every tensor is drawn from its own generator seeded by
+reference architecture, drawn from PyTorch's own default initialisation distributions
+(conv/linear: U(+-1/sqrt(fan_in)) for weight and bias; norms: 1 / 0, lightly perturbed).  Every tensor is drawn from its own generator seeded by
 crc32(key) ^ seed, so a fixture never depends on module construction order and
 no multi-MB weight file has to be committed.
 
@@ -151,21 +152,49 @@ def synth_tensor(key, shape, seed=0):
         return 0.1 * torch.randn(shape, generator=g)
     if leaf == "running_var":
         return 0.5 + torch.rand(shape, generator=g)
-    if len(shape) == 1:
-        is_norm_scale = leaf == "weight"
-        if is_norm_scale:
-            return 1.0 + 0.1 * torch.randn(shape, generator=g)
-        return 0.05 * torch.randn(shape, generator=g)
     fan_in = 1
     for d in shape[1:]:
         fan_in *= d
-    gain = 1.0
-    if key.startswith("classifier.12") or key == "classifier.8.weight" and shape[1] == 256:
-        gain = 3.0  # spread the tag logits so the sort has structure
-    return (gain / fan_in ** 0.5) * torch.randn(shape, generator=g)
+    if len(shape) == 1:
+        if _is_norm(key):
+            # torch initialises norms to (1, 0); perturb so gamma/beta paths are exercised
+            if leaf == "weight":
+                return 1.0 + 0.1 * torch.randn(shape, generator=g)
+            return 0.1 * torch.randn(shape, generator=g)
+        # conv / linear bias: torch default U(-1/sqrt(fan_in), 1/sqrt(fan_in)) of the matching weight
+        bound = 1.0 / _FAN_IN.get(key, 256) ** 0.5
+        return (torch.rand(shape, generator=g) * 2.0 - 1.0) * bound
+    # conv / linear weight: torch default kaiming_uniform_(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+    bound = 1.0 / fan_in ** 0.5
+    return (torch.rand(shape, generator=g) * 2.0 - 1.0) * bound
+
+
+_FAN_IN = {}
+
+
+def _is_norm(key):
+    stem = key.rsplit(".", 1)[0]
+    last = stem.rsplit(".", 1)[-1]
+    if last in ("norm1", "norm2", "group_norm", "conv_norm_out", "norm"):
+        return True
+    if stem == "feature_compress.1":
+        return True
+    if stem.startswith("classifier."):
+        return int(last) % 4 == 1          # classifier.{1,5,9} are LayerNorms
+    return False
+
+
+def _note_fan_in(manifest):
+    for k, s in manifest.items():
+        if k.endswith(".weight") and len(s) >= 2:
+            f = 1
+            for d in s[1:]:
+                f *= d
+            _FAN_IN[k[:-len("weight")] + "bias"] = f
 
 
 def synth_state_dict(manifest, seed=0):
+    _note_fan_in(manifest)
     return {k: synth_tensor(k, s, seed) for k, s in manifest.items()}
 
 
