@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--tags", type=int, default=10000)
     p.add_argument("--encode-only", action="store_true", help="BASELINE configs[1]: encoder only")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--generic-conv", action="store_true", help="A/B: disable the halo-tile 3x3 kernel")
     p.add_argument("--cpu-sample-res", type=int, default=1024)
     return p.parse_args()
 
@@ -98,6 +99,8 @@ def main():
     dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(a.tags), seed=1), strict=False)
     dec = dec.to(dev).eval()
     pipe = EncodeTagPipeline(vae_model, dec)
+    if a.generic_conv:
+        pipe.ctx.call("vt_set_flag", 0, 0)
 
     B = a.batch
     # synthetic inputs, resident in HBM before the timed region; distinct per rank (global batch = world*B)
@@ -126,7 +129,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    n = 3
+    n = prof_ctx.lib.vt_profile_num_configs()
     launches = (ctypes.c_longlong * n)()
     tot_ms = (ctypes.c_double * n)()
     tot_fl = (ctypes.c_double * n)()

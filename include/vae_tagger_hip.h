@@ -78,12 +78,19 @@ int vt_encode_tag(vt_context* ctx, const float* x_nchw, int B, int H, int W, flo
 /* algorithmic FLOPs of one encoder forward at HxW -- for roofline reporting */
 double vt_encoder_flops(const vt_context* ctx, int H, int W);
 
+/* ---- options ---------------------------------------------------------------------------------
+ * flag 0: 1 (default) = 3x3 stride-1 convs use the halo-tile kernel (conv3x3_halo.hip),
+ *         0 = every contraction uses the generic implicit-GEMM kernel (conv_gemm.hip).
+ */
+int vt_set_flag(vt_context* ctx, int flag, int value);
+
 /* ---- measurement ----------------------------------------------------------------------------
  * Between vt_profile_begin and vt_profile_end every launch of the implicit-GEMM MFMA kernel is
  * bracketed by hipEvents recorded on the launch stream.  vt_profile_end synchronises on them and
- * returns, per tile configuration (3 of them), the launch count, summed duration (ms) and summed
+ * returns, per kernel/tile configuration (vt_profile_num_configs() of them), the launch count, summed duration (ms) and summed
  * ALGORITHMIC FLOPs (2*B*Hout*Wout*Cout*taps*Cin).  bench.py derives roofline.achieved from these.
  */
+int vt_profile_num_configs(void);
 int vt_profile_begin(vt_context* ctx);
 int vt_profile_end(vt_context* ctx, int max_cfg, long long* launches, double* total_ms, double* total_flops,
                    const char** kernel_names);

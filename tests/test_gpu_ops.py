@@ -30,11 +30,23 @@ CONV_CASES = [
     (1, 128, 256, 12, 20, 1, 1, 0, 0),      # conv_shortcut 1x1
     (1, 512, 32, 16, 24, 3, 1, 1, 1),       # conv_out-shaped (Cout=32 config)
     (3, 64, 64, 5, 7, 3, 1, 1, 1),          # Cin = one K chunk, tiny image
+    (1, 128, 128, 40, 50, 3, 1, 1, 1),      # halo kernel <4,2>: several 32x16 tiles, ragged right/bottom edges
+    (2, 256, 256, 33, 17, 3, 1, 1, 1),      # halo kernel <2,4>: ragged 16x16 tiles
+    (1, 512, 512, 16, 16, 3, 1, 1, 1),      # 16 channel chunks, two cout tiles
+    (1, 32, 128, 9, 9, 3, 1, 1, 1),         # single channel chunk (last-chunk path only)
 ]
 
 
+@pytest.fixture(params=["halo", "generic"])
+def conv_kernel(request, ops):
+    """3x3 stride-1 convs have two kernels: the halo-tile one (default) and the generic implicit GEMM."""
+    ops.ctx.call("vt_set_flag", 0, 1 if request.param == "halo" else 0)
+    yield request.param
+    ops.ctx.call("vt_set_flag", 0, 1)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W,k,stride,plo,phi", CONV_CASES)
-def test_conv2d_matches_torch(ops, B, Cin, Cout, H, W, k, stride, plo, phi):
+def test_conv2d_matches_torch(ops, conv_kernel, B, Cin, Cout, H, W, k, stride, plo, phi):
     x = bf16_round(_rand((B, Cin, H, W), 1))
     w = bf16_round(_rand((Cout, Cin, k, k), 2, (Cin * k * k) ** -0.5))
     b = _rand((Cout,), 3, 0.1)
@@ -49,7 +61,7 @@ def test_conv2d_matches_torch(ops, B, Cin, Cout, H, W, k, stride, plo, phi):
     assert torch.allclose(got, ref - res - b.view(1, -1, 1, 1), rtol=1e-4, atol=2e-4)
 
 
-def test_conv2d_identity_weights_asymmetric_input(ops):
+def test_conv2d_identity_weights_asymmetric_input(ops, conv_kernel):
     """A = I style check with an asymmetric operand: catches a transposed C/D map or a swapped tap."""
     Cin = Cout = 128
     x = torch.arange(2 * Cin * 6 * 10, dtype=torch.float32).reshape(2, Cin, 6, 10) % 251 - 125.0

@@ -22,7 +22,7 @@ struct HostTensor {
     int64_t numel() const { int64_t n = 1; for (auto d : shape) n *= d; return n; }
 };
 
-struct ConvW { const bf16_t* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0; };
+struct ConvW { const bf16_t* w = nullptr; const bf16_t* wp = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0; };   // w: [cout][tap][cin]; wp: halo-kernel packing
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
 struct ResnetW { NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
 struct AttnW { NormW gn; const bf16_t *wqk = nullptr, *wv = nullptr, *wo = nullptr; const float *bqk = nullptr, *bv = nullptr, *bo = nullptr; int c = 0; };
@@ -76,6 +76,8 @@ struct vt_context {
     EncoderW enc;
     DecoderWeights dec;
     bool dec_configured = false, dec_finalized = false;
+    int use_halo_conv = 1;          // vt_set_flag(ctx, 0, v)
+    void* op_scratch = nullptr; size_t op_scratch_bytes = 0;
 
     // optional per-launch timing of the MFMA kernel (HIP events on the launch stream)
     struct ProfRec { hipEvent_t e0, e1; double flops; int cfg; };
@@ -134,6 +136,16 @@ int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, C
     out->b = (const float*)c->upload(b->v.data(), b->v.size() * 4);
     out->cin = cin; out->cout = cout; out->k = k;
     if (!out->w || !out->b) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+    if (k == 3 && vt_conv3x3_halo_supported(cin, cout)) {
+        // halo kernel: Wp[cin/32][tap][cout][32] so each K-step's weight tile is one contiguous block
+        std::vector<uint16_t> hp(p.size());
+        for (int o = 0; o < cout; ++o)
+            for (int t = 0; t < 9; ++t)
+                for (int i = 0; i < cin; ++i)
+                    hp[(((size_t)(i >> 5) * 9 + t) * cout + o) * 32 + (i & 31)] = p[((size_t)o * 9 + t) * cin + i];
+        out->wp = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
+        if (!out->wp) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+    }
     return VT_OK;
 }
 int get_norm(vt_context* c, const std::string& name, int ch, NormW* out) {
@@ -189,6 +201,23 @@ hipError_t launch_gemm(vt_context* c, const ConvGemmArgs& a, hipStream_t s) {
 
 struct GnScratch { float* partial; float* ss; };
 
+hipError_t launch_halo(vt_context* c, const Conv3x3Args& a, hipStream_t s) {
+    if (!c->profiling) return vt_launch_conv3x3_halo(a, s);
+    vt_context::ProfRec r;
+    r.e0 = c->next_event(); r.e1 = c->next_event();
+    if (!r.e0 || !r.e1) return hipErrorOutOfMemory;
+    r.flops = 2.0 * a.batch * (double)a.H * a.W * a.Cout * 9.0 * a.Cin;
+    r.cfg = vt_conv3x3_halo_config(a);
+    hipError_t e = hipEventRecord(r.e0, s);
+    if (e != hipSuccess) return e;
+    e = vt_launch_conv3x3_halo(a, s);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(r.e1, s);
+    if (e != hipSuccess) return e;
+    c->prof.push_back(r);
+    return hipSuccess;
+}
+
 int run_gn(vt_context* c, const void* x, int is_f32, int B, int HW, const NormW& n, int groups, int silu, bf16_t* y,
            const GnScratch& g, hipStream_t s) {
     int nchunks = 0;
@@ -200,6 +229,13 @@ int run_gn(vt_context* c, const void* x, int is_f32, int B, int HW, const NormW&
 
 int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int Win, int stride, int pad, int Hout,
              int Wout, const float* res, float* o32, bf16_t* o16, hipStream_t s) {
+    if (c->use_halo_conv && w.wp && w.k == 3 && stride == 1 && pad == 1 && Hout == Hin && Wout == Win) {
+        Conv3x3Args h{};
+        h.X = x; h.Wp = w.wp; h.bias = w.b; h.res = res; h.out_f32 = o32; h.out_bf16 = o16; h.zeros = c->zeros;
+        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
+        HIPCK(c, launch_halo(c, h, s), "conv3x3_halo");
+        return VT_OK;
+    }
     ConvGemmArgs a{};
     a.X = x; a.W = w.w; a.bias = w.b; a.res = res; a.out_f32 = o32; a.out_bf16 = o16; a.zeros = c->zeros;
     a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cin = w.cin; a.Cout = w.cout; a.Wrows = w.cout;
@@ -325,6 +361,7 @@ void vt_destroy(vt_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->op_scratch) (void)hipFree(c->op_scratch);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->zeros) (void)hipFree(c->zeros);
     delete c;
@@ -705,6 +742,14 @@ int vt_encode_tag(vt_context* c, const float* x, int B, int H, int W, float* lat
     return vt_decode_logits(c, lat, B, p.hl, p.wl, logits, rest, ws_bytes - lat_bytes, stream);
 }
 
+int vt_set_flag(vt_context* c, int flag, int value) {
+    if (!c) return VT_ERR_INVALID;
+    if (flag == 0) { c->use_halo_conv = value != 0; return VT_OK; }
+    return c->fail(VT_ERR_INVALID, "vt_set_flag: unknown flag %d", flag);
+}
+
+int vt_profile_num_configs(void) { return VT_NUM_MFMA_CONFIGS; }
+
 // ---- profiling ----------------------------------------------------------------------------------
 int vt_profile_begin(vt_context* c) {
     if (!c) return VT_ERR_INVALID;
@@ -716,8 +761,8 @@ int vt_profile_end(vt_context* c, int max_cfg, long long* launches, double* tota
                    const char** names) {
     if (!c) return VT_ERR_INVALID;
     c->profiling = false;
-    if (max_cfg < 3 || !launches || !total_ms || !total_flops) return c->fail(VT_ERR_INVALID, "vt_profile_end: need room for 3 configurations");
-    for (int i = 0; i < 3; ++i) { launches[i] = 0; total_ms[i] = 0; total_flops[i] = 0; if (names) names[i] = vt_conv_gemm_config_name(i); }
+    if (max_cfg < VT_NUM_MFMA_CONFIGS || !launches || !total_ms || !total_flops) return c->fail(VT_ERR_INVALID, "vt_profile_end: need room for %d configurations", VT_NUM_MFMA_CONFIGS);
+    for (int i = 0; i < VT_NUM_MFMA_CONFIGS; ++i) { launches[i] = 0; total_ms[i] = 0; total_flops[i] = 0; if (names) names[i] = vt_conv_gemm_config_name(i); }
     for (auto& r : c->prof) {
         HIPCK(c, hipEventSynchronize(r.e1), "hipEventSynchronize");
         float ms = 0.f;
@@ -736,6 +781,21 @@ int vt_op_conv2d(vt_context* c, const void* x, const void* w, const float* bias,
     if (stride < 1 || pad_lo < 0 || pad_hi < 0) return c->fail(VT_ERR_INVALID, "vt_op_conv2d: bad stride/pad");
     const int Hout = (Hin + pad_lo + pad_hi - ksize) / stride + 1, Wout = (Win + pad_lo + pad_hi - ksize) / stride + 1;
     if (Hout < 1 || Wout < 1) return c->fail(VT_ERR_INVALID, "vt_op_conv2d: empty output");
+    if (c->use_halo_conv && ksize == 3 && stride == 1 && pad_lo == 1 && pad_hi == 1 && vt_conv3x3_halo_supported(Cin, Cout)) {
+        const size_t need = (size_t)Cout * 9 * Cin * 2;
+        if (c->op_scratch_bytes < need) {
+            if (c->op_scratch) (void)hipFree(c->op_scratch);
+            c->op_scratch = nullptr; c->op_scratch_bytes = 0;
+            HIPCK(c, hipMalloc(&c->op_scratch, need), "hipMalloc(op scratch)");
+            c->op_scratch_bytes = need;
+        }
+        HIPCK(c, vt_launch_repack_ohwi_to_halo((const bf16_t*)w, (bf16_t*)c->op_scratch, Cin, Cout, (hipStream_t)stream), "repack");
+        Conv3x3Args h{};
+        h.X = (const bf16_t*)x; h.Wp = (const bf16_t*)c->op_scratch; h.bias = bias; h.res = res; h.out_f32 = o32;
+        h.out_bf16 = (bf16_t*)o16; h.zeros = c->zeros; h.batch = B; h.H = Hin; h.W = Win; h.Cin = Cin; h.Cout = Cout;
+        HIPCK(c, launch_halo(c, h, (hipStream_t)stream), "vt_op_conv2d(halo)");
+        return VT_OK;
+    }
     ConvGemmArgs a{};
     a.X = (const bf16_t*)x; a.W = (const bf16_t*)w; a.bias = bias; a.res = res; a.out_f32 = o32; a.out_bf16 = (bf16_t*)o16;
     a.zeros = c->zeros; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cin = Cin; a.Cout = Cout; a.Wrows = Cout;

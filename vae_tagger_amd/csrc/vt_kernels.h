@@ -31,6 +31,23 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s);
 // which tile configuration the dispatcher picks for these args: 0 = 128x32, 1 = 256x128, 2 = 256x256
 int vt_conv_gemm_config(const ConvGemmArgs& a);
 const char* vt_conv_gemm_config_name(int cfg);
+constexpr int VT_NUM_MFMA_CONFIGS = 5;   // 0..2 conv_gemm tiles, 3..4 conv3x3_halo tiles
+
+// 3x3 stride-1 pad-1 conv, halo-tile kernel (conv3x3_halo.hip)
+struct Conv3x3Args {
+    const bf16_t* X;        // NHWC bf16 [batch][H][W][Cin]
+    const bf16_t* Wp;       // packed [Cin/32][9][Cout][32] bf16
+    const float* bias;      // [Cout] or null
+    const float* res;       // optional fp32 residual [batch][H][W][Cout]
+    float* out_f32;         // optional
+    bf16_t* out_bf16;       // optional
+    const void* zeros;
+    int batch, H, W, Cin, Cout;
+};
+bool vt_conv3x3_halo_supported(int Cin, int Cout);
+int vt_conv3x3_halo_config(const Conv3x3Args& a);
+hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s);
+hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w_ohwi, bf16_t* wp, int Cin, int Cout, hipStream_t s);
 
 // conv_in: fp32 NCHW image -> NHWC 128-channel fp32 (+ optional bf16) rows, direct fp32 conv 3x3 p1.
 hipError_t vt_launch_conv_in(const float* x_nchw, const float* w_packed /*[27][Cout]*/, const float* bias,
