@@ -81,6 +81,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
 /* ---- options ---------------------------------------------------------------------------------
  * flag 0: 1 (default) = 3x3 stride-1 convs use the halo-tile kernel (conv3x3_halo.hip),
  *         0 = every contraction uses the generic implicit-GEMM kernel (conv_gemm.hip).
+ * flag 1: 1 (default) = conv epilogues emit GroupNorm partial statistics for the next norm,
+ *         0 = every GroupNorm runs its own statistics pass.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 
@@ -102,6 +104,13 @@ int vt_profile_end(vt_context* ctx, int max_cfg, long long* launches, double* to
 int vt_op_conv2d(vt_context* ctx, const void* x_bf16_nhwc, const void* w_bf16_ohwi, const float* bias,
                  const float* residual_f32, float* out_f32, void* out_bf16, int B, int Hin, int Win, int Cin,
                  int Cout, int ksize, int stride, int pad_lo, int pad_hi, void* stream);
+/* conv2d whose epilogue also produces the GroupNorm statistics of its output: returns per (image, channel)
+ * (scale, shift) with GroupNorm(out) = out*scale + shift.  The encoder uses this fusion between layers. */
+size_t vt_op_conv2d_gn_workspace_bytes(int B, int Hout, int Wout, int Cout);
+int vt_op_conv2d_gn(vt_context* ctx, const void* x_bf16_nhwc, const void* w_bf16_ohwi, const float* bias,
+                    const float* residual_f32, float* out_f32, void* out_bf16, int B, int Hin, int Win, int Cin,
+                    int Cout, int ksize, int stride, int pad_lo, int pad_hi, int groups, float eps, const float* gamma,
+                    const float* beta, float* scale_shift_out, void* workspace, void* stream);
 int vt_op_gemm_nt(vt_context* ctx, const void* a_bf16, const void* b_bf16, const float* bias, float* out_f32,
                   void* out_bf16, int batch, int M, int N, int K, int lda, int ldb, int ldo, long long a_bs,
                   long long b_bs, long long o_bs, float alpha, int bias_per_row, void* stream);

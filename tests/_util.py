@@ -71,6 +71,27 @@ class Ops:
             outs.append(nchw(o16.float().cpu()))
         return outs[0] if len(outs) == 1 else tuple(outs)
 
+    def conv2d_gn(self, x_nchw, w_oihw, bias, gamma, beta, residual_nchw=None, stride=1, pad_lo=1, pad_hi=1, groups=32, eps=1e-6):
+        """-> (conv output fp32 NCHW, scale_shift [B,Cout,2]) with the statistics taken in the conv epilogue."""
+        B, Cin, H, W = x_nchw.shape
+        Cout, _, k, _ = w_oihw.shape
+        x = nhwc(x_nchw).to(self.dev, torch.bfloat16)
+        w = w_oihw.permute(0, 2, 3, 1).contiguous().to(self.dev, torch.bfloat16)
+        b = bias.to(self.dev, torch.float32).contiguous()
+        Ho = (H + pad_lo + pad_hi - k) // stride + 1
+        Wo = (W + pad_lo + pad_hi - k) // stride + 1
+        r = nhwc(residual_nchw).to(self.dev, torch.float32) if residual_nchw is not None else None
+        o32 = torch.zeros((B, Ho, Wo, Cout), device=self.dev, dtype=torch.float32)
+        ss = torch.zeros((B, Cout, 2), device=self.dev, dtype=torch.float32)
+        n = self.ctx.lib.vt_op_conv2d_gn_workspace_bytes(B, Ho, Wo, Cout)
+        ws = torch.empty(n + 256, device=self.dev, dtype=torch.uint8)
+        g = gamma.to(self.dev, torch.float32).contiguous()
+        bt = beta.to(self.dev, torch.float32).contiguous()
+        self.ctx.call("vt_op_conv2d_gn", vp(x), vp(w), vp(b), vp(r), vp(o32), None, B, H, W, Cin, Cout, k, stride, pad_lo,
+                      pad_hi, groups, float(eps), vp(g), vp(bt), vp(ss), vp(ws), self.stream)
+        torch.cuda.synchronize()
+        return nchw(o32.cpu()), ss.cpu()
+
     def gemm_nt(self, a, b, bias=None, alpha=1.0, bias_per_row=False, out_bf16=False, lda=None, ldb=None, ldo=None):
         """a [batch,M,K] fp32, b [batch or 1,N,K] fp32 -> [batch,M,N]"""
         batch, M, K = a.shape

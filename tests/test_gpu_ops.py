@@ -73,6 +73,26 @@ def test_conv2d_identity_weights_asymmetric_input(ops, conv_kernel):
         assert torch.equal(got, ref), f"tap {tap}"
 
 
+GN_EPI_CASES = [(2, 128, 128, 40, 50, 3, 1, 1, 1), (1, 128, 256, 33, 17, 3, 1, 1, 1), (1, 256, 512, 20, 20, 3, 1, 1, 1),
+                (2, 128, 128, 17, 22, 3, 2, 0, 1), (1, 256, 512, 12, 20, 1, 1, 0, 0)]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,stride,plo,phi", GN_EPI_CASES)
+def test_conv_epilogue_groupnorm_statistics(ops, conv_kernel, B, Cin, Cout, H, W, k, stride, plo, phi):
+    """GroupNorm (scale, shift) produced by the conv epilogue == GroupNorm of the conv output."""
+    x = bf16_round(_rand((B, Cin, H, W), 21))
+    w = bf16_round(_rand((Cout, Cin, k, k), 22, (Cin * k * k) ** -0.5))
+    b = _rand((Cout,), 23, 0.1) + 3.0                         # a large common offset: mean >> std inside groups
+    g = 1 + 0.1 * _rand((Cout,), 24)
+    bt = 0.1 * _rand((Cout,), 25)
+    out, ss = ops.conv2d_gn(x, w, b, g, bt, stride=stride, pad_lo=plo, pad_hi=phi)
+    ref = F.conv2d(F.pad(x, (plo, phi, plo, phi)), w, b, stride=stride)
+    assert torch.allclose(out, ref, rtol=1e-4, atol=2e-4)
+    want = F.group_norm(ref, 32, g, bt, eps=1e-6)
+    got = out * ss[:, :, 0].view(B, Cout, 1, 1) + ss[:, :, 1].view(B, Cout, 1, 1)
+    assert torch.allclose(got, want, rtol=1e-3, atol=1e-3), (got - want).abs().max()
+
+
 @pytest.mark.parametrize("batch,M,N,K", [(1, 300, 200, 512), (2, 64, 512, 128), (1, 257, 108, 72), (1, 100, 104, 1000)])
 def test_gemm_nt_matches_torch(ops, batch, M, N, K):
     a = bf16_round(_rand((batch, M, K), 5))
@@ -123,7 +143,7 @@ def test_conv_in_matches_torch(ops, H, W):
     assert torch.allclose(got16, bf16_round(ref), rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("rows,n", [(5, 64), (3, 108), (2, 4096), (1, 16384)])
+@pytest.mark.parametrize("rows,n", [(5, 64), (3, 108), (4, 101), (2, 4096), (2, 5000), (1, 16384), (1, 20000)])
 def test_softmax_rows(ops, rows, n):
     s = _rand((rows, n), 16) * 3
     s[0, n // 2] = 40.0                                      # a spike: max-subtraction must hold

@@ -77,6 +77,7 @@ struct vt_context {
     DecoderWeights dec;
     bool dec_configured = false, dec_finalized = false;
     int use_halo_conv = 1;          // vt_set_flag(ctx, 0, v)
+    int fuse_gn_stats = 1;          // vt_set_flag(ctx, 1, v)
     void* op_scratch = nullptr; size_t op_scratch_bytes = 0;
 
     // optional per-launch timing of the MFMA kernel (HIP events on the launch stream)
@@ -199,7 +200,6 @@ hipError_t launch_gemm(vt_context* c, const ConvGemmArgs& a, hipStream_t s) {
     return hipSuccess;
 }
 
-struct GnScratch { float* partial; float* ss; };
 
 hipError_t launch_halo(vt_context* c, const Conv3x3Args& a, hipStream_t s) {
     if (!c->profiling) return vt_launch_conv3x3_halo(a, s);
@@ -218,21 +218,35 @@ hipError_t launch_halo(vt_context* c, const Conv3x3Args& a, hipStream_t s) {
     return hipSuccess;
 }
 
+// GroupNorm bookkeeping: `partial` holds (n, mean, M2) triples for the tensor that will be normalised next,
+// written either by the producing conv's epilogue (stats_parts > 0) or by the standalone stats pass.
+struct GnState {
+    float* partial = nullptr; float* ss = nullptr;
+    int parts = 0;            // triples per (image, group) currently in `partial`; 0 = none
+};
+
+// y = act(GroupNorm(x)) as bf16 rows.  Uses epilogue-produced partials when present.
 int run_gn(vt_context* c, const void* x, int is_f32, int B, int HW, const NormW& n, int groups, int silu, bf16_t* y,
-           const GnScratch& g, hipStream_t s) {
-    int nchunks = 0;
-    HIPCK(c, vt_launch_gn_stats(x, is_f32, B, HW, n.c, groups, g.partial, &nchunks, s), "gn_stats");
-    HIPCK(c, vt_launch_gn_finalize(g.partial, nchunks, B, HW, n.c, groups, 1e-6f, n.g, n.b, g.ss, s), "gn_finalize");
+           GnState& g, hipStream_t s) {
+    int parts = g.parts;
+    if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, is_f32, B, HW, n.c, groups, g.partial, &parts, s), "gn_stats");
+    g.parts = 0;
+    HIPCK(c, vt_launch_gn_finalize(g.partial, parts, B, n.c, groups, 1e-6f, n.g, n.b, g.ss, s), "gn_finalize");
     HIPCK(c, vt_launch_gn_apply(x, is_f32, g.ss, y, B, HW, n.c, silu, s), "gn_apply");
     return VT_OK;
 }
 
+// `gn`: if non-null, the epilogue also writes GroupNorm partials of the output (cpg = cout / groups)
 int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int Win, int stride, int pad, int Hout,
-             int Wout, const float* res, float* o32, bf16_t* o16, hipStream_t s) {
+             int Wout, const float* res, float* o32, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32) {
+    const int cpg = w.cout / groups;
+    const bool fuse = gn && c->fuse_gn_stats && (cpg == 4 || cpg == 8 || cpg == 16);
+    if (gn) gn->parts = 0;
     if (c->use_halo_conv && w.wp && w.k == 3 && stride == 1 && pad == 1 && Hout == Hin && Wout == Win) {
         Conv3x3Args h{};
         h.X = x; h.Wp = w.wp; h.bias = w.b; h.res = res; h.out_f32 = o32; h.out_bf16 = o16; h.zeros = c->zeros;
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
+        if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout); }
         HIPCK(c, launch_halo(c, h, s), "conv3x3_halo");
         return VT_OK;
     }
@@ -243,6 +257,9 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     a.ldx = w.cin; a.ldw = w.k * w.k * w.cin; a.ldo = w.cout; a.ldr = w.cout;
     a.x_bs = (long long)Hin * Win * w.cin; a.w_bs = 0; a.o_bs = (long long)Hout * Wout * w.cout; a.r_bs = a.o_bs;
     a.batch = B; a.alpha = 1.f; a.bias_mode = 1; a.out_mode = 0;
+    if (fuse && w.cout > 32 && (w.cout % (w.cout <= 128 ? 128 : 256)) == 0) {
+        a.gn_partial = gn->partial; a.gn_cpg = cpg; gn->parts = vt_conv_gemm_ptiles(Hout * Wout, w.cout);
+    }
     HIPCK(c, launch_gemm(c, a, s), "conv_gemm");
     return VT_OK;
 }
@@ -268,7 +285,7 @@ AttnScratch carve_attn(char* p, int B, int S, int C) {
 // diffusers Attention for the VAE mid block: 1 head, dim_head = C, scale 1/sqrt(C).
 // x16: group-normed tokens [B][S][C] bf16.  out = to_out(softmax(q k^T / sqrt(C)) v) + residual.
 int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const float* res, float* out32, int B, int S,
-                  const AttnScratch& sc, hipStream_t s) {
+                  const AttnScratch& sc, hipStream_t s, GnState* gn = nullptr, int groups = 32) {
     const int C = w.c;
     const int ld = (S + 7) / 8 * 8;
     ConvGemmArgs a{};
@@ -300,6 +317,13 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const float*
     a.X = sc.o; a.W = w.wo; a.bias = w.bo; a.bias_mode = 1; a.res = res; a.out_f32 = out32; a.out_bf16 = nullptr;
     a.Win = a.Wout = S; a.Cin = C; a.Cout = C; a.Wrows = C; a.ldx = C; a.ldw = C; a.ldo = C; a.ldr = C;
     a.x_bs = (long long)S * C; a.w_bs = 0; a.o_bs = a.x_bs; a.r_bs = a.x_bs; a.batch = B; a.alpha = 1.f;
+    if (gn) {
+        gn->parts = 0;
+        const int cpg = C / groups;
+        if (c->fuse_gn_stats && (cpg == 4 || cpg == 8 || cpg == 16) && C > 32 && (C % (C <= 128 ? 128 : 256)) == 0) {
+            a.gn_partial = gn->partial; a.gn_cpg = cpg; gn->parts = vt_conv_gemm_ptiles(S, C);
+        }
+    }
     HIPCK(c, launch_gemm(c, a, s), "attn out proj");
     return VT_OK;
 }
@@ -320,7 +344,11 @@ EncPlan plan_encoder(const EncoderW& e, int B, int H, int W) {
         const size_t n = (size_t)hh * ww * ch;
         if (n > p.max_elems) p.max_elems = n;
         if (ch > p.max_c) p.max_c = ch;
-        const int ck = vt_gn_max_chunks(hh * ww, ch);
+        int ck = vt_gn_max_chunks(hh * ww, ch);
+        const int t1 = vt_conv_gemm_ptiles(hh * ww, ch), t2 = vt_conv3x3_halo_tiles(hh, ww, ch), t3 = vt_conv_in_parts(hh, ww);
+        if (t3 > ck) ck = t3;
+        if (t1 > ck) ck = t1;
+        if (t2 > ck) ck = t2;
         if (ck > p.max_chunks) p.max_chunks = ck;
     };
     note(h, w, e.block_out[0]);
@@ -332,7 +360,7 @@ EncPlan plan_encoder(const EncoderW& e, int B, int H, int W) {
     const int S = h * w, C = e.block_out.back();
     const size_t slack = 4096;
     p.total = 3 * align_up(p.max_elems * B * 4 + slack) + 3 * align_up(p.max_elems * B * 2 + slack) +
-              align_up((size_t)B * p.max_chunks * e.groups * 2 * 4) + align_up((size_t)B * p.max_c * 2 * 4) +
+              align_up((size_t)B * p.max_chunks * e.groups * 3 * 4) + align_up((size_t)B * p.max_c * 2 * 4) +
               attn_scratch_bytes(B, S, C) + ALIGN;
     return p;
 }
@@ -512,8 +540,8 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
     float* f32[3]; bf16_t* b16[3];
     for (int i = 0; i < 3; ++i) { f32[i] = (float*)q; q += align_up(p.max_elems * B * 4 + slack); }
     for (int i = 0; i < 3; ++i) { b16[i] = (bf16_t*)q; q += align_up(p.max_elems * B * 2 + slack); }
-    GnScratch gn;
-    gn.partial = (float*)q; q += align_up((size_t)B * p.max_chunks * e.groups * 2 * 4);
+    GnState gn;
+    gn.partial = (float*)q; q += align_up((size_t)B * p.max_chunks * e.groups * 3 * 4);
     gn.ss = (float*)q; q += align_up((size_t)B * p.max_c * 2 * 4);
     const int C = e.block_out.back();
     AttnScratch as = carve_attn(q, B, p.hl * p.wl, C);
@@ -524,7 +552,14 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
     bf16_t* tmid = b16[1];                         // conv1 output / bf16 copy of h after a downsample
     bf16_t* hb = b16[2];                           // bf16 copy of h feeding a downsample conv
     int h = H, w = W;
-    HIPCK(c, vt_launch_conv_in(x, e.conv_in_w, e.conv_in_b, f32[cur], nullptr, B, H, W, e.block_out[0], s), "conv_in");
+    {
+        const int cpg0 = e.block_out[0] / e.groups;
+        const bool fuse0 = c->fuse_gn_stats && (cpg0 % 4) == 0;
+        int parts = 0;
+        HIPCK(c, vt_launch_conv_in(x, e.conv_in_w, e.conv_in_b, f32[cur], nullptr, fuse0 ? gn.partial : nullptr, cpg0, &parts,
+                                   B, H, W, e.block_out[0], s), "conv_in");
+        gn.parts = fuse0 ? parts : 0;
+    }
 
     // one ResnetBlock2D: h <- conv2(silu(gn(conv1(silu(gn(h)))))) + shortcut(h)
     auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out) -> int {
@@ -536,13 +571,13 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             res = f32[scb];
         }
         if ((rr = run_gn(c, f32[cur], 1, B, h * w, rw.n1, e.groups, 1, act, gn, s))) return rr;
-        if ((rr = run_conv(c, rw.c1, act, B, h, w, 1, 1, h, w, nullptr, nullptr, tmid, s))) return rr;
+        if ((rr = run_conv(c, rw.c1, act, B, h, w, 1, 1, h, w, nullptr, nullptr, tmid, s, &gn, e.groups))) return rr;
         if ((rr = run_gn(c, tmid, 0, B, h * w, rw.n2, e.groups, 1, act, gn, s))) return rr;
         if (want_bf16_out) {
-            // the only consumer is the downsample conv (bf16 operand): skip the fp32 copy of h
+            // the only consumer is the downsample conv (bf16 operand, no norm): skip the fp32 copy of h and the stats
             return run_conv(c, rw.c2, act, B, h, w, 1, 1, h, w, res, nullptr, hb, s);
         }
-        if ((rr = run_conv(c, rw.c2, act, B, h, w, 1, 1, h, w, res, f32[nxt], nullptr, s))) return rr;
+        if ((rr = run_conv(c, rw.c2, act, B, h, w, 1, 1, h, w, res, f32[nxt], nullptr, s, &gn, e.groups))) return rr;
         cur = nxt;
         return VT_OK;
     };
@@ -561,7 +596,7 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             const int ho = h / 2, wo = w / 2;
             const int nxt = (cur + 1) % 3;
             const bool next_has_sc = (i + 1 < e.stages.size()) && e.stages[i + 1].res[0].has_sc;
-            if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], next_has_sc ? tmid : nullptr, s))) return r;
+            if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], next_has_sc ? tmid : nullptr, s, &gn, e.groups))) return r;
             // the bf16 copy lives in tmid until the next resnet's conv1 overwrites it; the shortcut conv runs first
             h16 = next_has_sc ? tmid : nullptr;
             cur = nxt; h = ho; w = wo;
@@ -571,7 +606,7 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
     {
         const int S = h * w, nxt = (cur + 1) % 3;
         if ((r = run_gn(c, f32[cur], 1, B, S, e.attn.gn, e.groups, 0, act, gn, s))) return r;
-        if ((r = run_attention(c, e.attn, act, f32[cur], f32[nxt], B, S, as, s))) return r;
+        if ((r = run_attention(c, e.attn, act, f32[cur], f32[nxt], B, S, as, s, &gn, e.groups))) return r;
         cur = nxt;
     }
     if ((r = resnet(e.mid1, nullptr, false))) return r;
@@ -745,6 +780,7 @@ int vt_encode_tag(vt_context* c, const float* x, int B, int H, int W, float* lat
 int vt_set_flag(vt_context* c, int flag, int value) {
     if (!c) return VT_ERR_INVALID;
     if (flag == 0) { c->use_halo_conv = value != 0; return VT_OK; }
+    if (flag == 1) { c->fuse_gn_stats = value != 0; return VT_OK; }
     return c->fail(VT_ERR_INVALID, "vt_set_flag: unknown flag %d", flag);
 }
 
@@ -806,6 +842,47 @@ int vt_op_conv2d(vt_context* c, const void* x, const void* w, const float* bias,
     return VT_OK;
 }
 
+size_t vt_op_conv2d_gn_workspace_bytes(int B, int Hout, int Wout, int Cout) {
+    if (B <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0) return 0;
+    int parts = vt_conv_gemm_ptiles(Hout * Wout, Cout);
+    const int t2 = vt_conv3x3_halo_tiles(Hout, Wout, Cout);
+    if (t2 > parts) parts = t2;
+    return align_up((size_t)B * parts * 64 * 3 * 4);
+}
+
+// conv + the GroupNorm (scale, shift) of its OUTPUT from the epilogue partials (no extra pass over the output)
+int vt_op_conv2d_gn(vt_context* c, const void* x, const void* w, const float* bias, const float* res, float* o32, void* o16,
+                    int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int pad_lo, int pad_hi, int groups,
+                    float eps, const float* gamma, const float* beta, float* scale_shift, void* ws, void* stream) {
+    if (!c) return VT_ERR_INVALID;
+    if (!gamma || !beta || !scale_shift || !ws || groups < 1 || groups > 64 || Cout % groups) return c->fail(VT_ERR_INVALID, "vt_op_conv2d_gn: bad argument");
+    const int cpg = Cout / groups;
+    if (cpg != 4 && cpg != 8 && cpg != 16) return c->fail(VT_ERR_INVALID, "vt_op_conv2d_gn: channels per group must be 4, 8 or 16");
+    const int Hout = (Hin + pad_lo + pad_hi - ksize) / stride + 1, Wout = (Win + pad_lo + pad_hi - ksize) / stride + 1;
+    ConvW cw; cw.cin = Cin; cw.cout = Cout; cw.k = ksize; cw.w = (const bf16_t*)w; cw.b = bias;
+    hipStream_t s = (hipStream_t)stream;
+    if (c->use_halo_conv && ksize == 3 && stride == 1 && pad_lo == 1 && pad_hi == 1 && vt_conv3x3_halo_supported(Cin, Cout)) {
+        const size_t need = (size_t)Cout * 9 * Cin * 2;
+        if (c->op_scratch_bytes < need) {
+            if (c->op_scratch) (void)hipFree(c->op_scratch);
+            c->op_scratch = nullptr; c->op_scratch_bytes = 0;
+            HIPCK(c, hipMalloc(&c->op_scratch, need), "hipMalloc(op scratch)");
+            c->op_scratch_bytes = need;
+        }
+        HIPCK(c, vt_launch_repack_ohwi_to_halo(cw.w, (bf16_t*)c->op_scratch, Cin, Cout, s), "repack");
+        cw.wp = (const bf16_t*)c->op_scratch;
+    }
+    if (!bias) return c->fail(VT_ERR_INVALID, "vt_op_conv2d_gn: bias required");
+    GnState gn; gn.partial = (float*)ws;
+    const int saved = c->fuse_gn_stats; c->fuse_gn_stats = 1;
+    int r = run_conv(c, cw, (const bf16_t*)x, B, Hin, Win, stride, pad_lo, Hout, Wout, res, o32, (bf16_t*)o16, s, &gn, groups);
+    c->fuse_gn_stats = saved;
+    if (r) return r;
+    if (gn.parts == 0) return c->fail(VT_ERR_INVALID, "vt_op_conv2d_gn: this shape has no stats epilogue");
+    HIPCK(c, vt_launch_gn_finalize(gn.partial, gn.parts, B, Cout, groups, eps, gamma, beta, scale_shift, s), "gn_finalize");
+    return VT_OK;
+}
+
 int vt_op_gemm_nt(vt_context* c, const void* A, const void* Bm, const float* bias, float* o32, void* o16, int batch, int M,
                   int N, int K, int lda, int ldb, int ldo, long long a_bs, long long b_bs, long long o_bs, float alpha,
                   int bias_per_row, void* stream) {
@@ -830,13 +907,13 @@ int vt_op_conv_in(vt_context* c, const float* x, const float* w_oihw, const floa
     HIPCK(c, hipMemcpy(hw.data(), w_oihw, hw.size() * 4, hipMemcpyDeviceToHost), "vt_op_conv_in copy");
     for (int o = 0; o < Cout; ++o) for (int k = 0; k < 27; ++k) pk[(size_t)k * Cout + o] = hw[(size_t)o * 27 + k];
     HIPCK(c, hipMemcpy(ws, pk.data(), pk.size() * 4, hipMemcpyHostToDevice), "vt_op_conv_in copy");
-    HIPCK(c, vt_launch_conv_in(x, (const float*)ws, bias, o32, (bf16_t*)o16, B, H, W, Cout, (hipStream_t)stream), "vt_op_conv_in");
+    HIPCK(c, vt_launch_conv_in(x, (const float*)ws, bias, o32, (bf16_t*)o16, nullptr, 0, nullptr, B, H, W, Cout, (hipStream_t)stream), "vt_op_conv_in");
     return VT_OK;
 }
 
 size_t vt_op_groupnorm_workspace_bytes(int B, int HW, int C) {
     if (B <= 0 || HW <= 0 || C < 8 || (C % 8)) return 0;
-    return align_up((size_t)B * vt_gn_max_chunks(HW, C) * 64 * 2 * 4) + align_up((size_t)B * C * 2 * 4);
+    return align_up((size_t)B * vt_gn_max_chunks(HW, C) * 64 * 3 * 4) + align_up((size_t)B * C * 2 * 4);
 }
 
 int vt_op_groupnorm(vt_context* c, const void* x, int x_dtype, int B, int HW, int C, int groups, float eps,
@@ -847,11 +924,11 @@ int vt_op_groupnorm(vt_context* c, const void* x, int x_dtype, int B, int HW, in
     if (groups > 64) return c->fail(VT_ERR_INVALID, "vt_op_groupnorm: groups > 64");
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)ws;
-    float* ss = (float*)((char*)ws + align_up((size_t)B * vt_gn_max_chunks(HW, C) * 64 * 2 * 4));
+    float* ss = (float*)((char*)ws + align_up((size_t)B * vt_gn_max_chunks(HW, C) * 64 * 3 * 4));
     int nchunks = 0;
     const int f = x_dtype == VT_F32;
     HIPCK(c, vt_launch_gn_stats(x, f, B, HW, C, groups, partial, &nchunks, s), "gn_stats");
-    HIPCK(c, vt_launch_gn_finalize(partial, nchunks, B, HW, C, groups, eps, gamma, beta, ss, s), "gn_finalize");
+    HIPCK(c, vt_launch_gn_finalize(partial, nchunks, B, C, groups, eps, gamma, beta, ss, s), "gn_finalize");
     HIPCK(c, vt_launch_gn_apply(x, f, ss, (bf16_t*)y, B, HW, C, silu, s), "gn_apply");
     return VT_OK;
 }

@@ -188,10 +188,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     const int HWp = a.H * a.W;
     const long long ob = (long long)b * HWp * a.Cout;
     const int x = tx0 + fr;
+    unsigned valid = 0;
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int y = ty0 + wp * 8 + j;
         if (y >= a.H || x >= a.W) continue;
+        valid |= 1u << j;
         const long long p = (long long)y * a.W + x;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
@@ -206,7 +208,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
                 h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
                 *(bf16x4*)(a.out_bf16 + o) = h;
             }
+            acc[i][j] = v;
         }
+    }
+    if (a.gn_partial) {
+        // GroupNorm statistics of this tile's outputs for the NEXT layer's norm (replaces a full read pass)
+        __syncthreads();                                   // every wave is done with the staging LDS
+        const int G = a.Cout / a.gn_cpg;
+        float* out = a.gn_partial + (((long long)b * (tiles_x * tiles_y) + tile) * G + c0 / a.gn_cpg) * 3;
+        vt_gn_epilogue_partials<TC, TP>(acc, valid, a.gn_cpg, wp, WP, wc * 64, BC, (float*)smem, out);
     }
 }
 
@@ -250,6 +260,11 @@ hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w, bf16_t* wp, int Cin, i
     return hipGetLastError();
 }
 
+int vt_conv3x3_halo_tiles(int H, int W, int Cout) {
+    const int rows = (Cout % 256) == 0 ? 16 : 32;
+    return ((W + TW - 1) / TW) * ((H + rows - 1) / rows);
+}
+
 bool vt_conv3x3_halo_supported(int Cin, int Cout) { return Cin >= 32 && (Cin % 32) == 0 && (Cout % 128) == 0; }
 
 int vt_conv3x3_halo_config(const Conv3x3Args& a) { return (a.Cout % 256) == 0 ? 4 : 3; }   // profile slots 3, 4
@@ -257,6 +272,7 @@ int vt_conv3x3_halo_config(const Conv3x3Args& a) { return (a.Cout % 256) == 0 ? 
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
     if (!a.X || !a.Wp || !a.zeros || (!a.out_f32 && !a.out_bf16)) return hipErrorInvalidValue;
     if (!vt_conv3x3_halo_supported(a.Cin, a.Cout) || a.batch <= 0 || a.H <= 0 || a.W <= 0) return hipErrorInvalidValue;
+    if (a.gn_partial && a.gn_cpg != 4 && a.gn_cpg != 8 && a.gn_cpg != 16) return hipErrorInvalidValue;
     if ((long long)a.H * a.W * a.Cin >= (1LL << 31)) return hipErrorInvalidValue;        // 32-bit per-image offsets
     if ((long long)(a.Cin / 32) * 9 * a.Cout * 32 >= (1LL << 31)) return hipErrorInvalidValue;
     if ((a.Cout % 256) == 0) return launch<2, 4>(a, s);     // 16x16 px x 256 couts

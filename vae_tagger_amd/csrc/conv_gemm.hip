@@ -169,10 +169,12 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const ConvGemmArgs a) {
     // ---- epilogue: lane holds couts cg..cg+3 (regs) of pixel p for every (i, j) tile.
     const long long ob = (long long)b * a.o_bs;
     const float* resb = a.res ? a.res + (long long)b * a.r_bs : nullptr;
+    unsigned valid = 0;
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int p = p0 + wp * (BP / WP) + j * 16 + frow;
         if (p >= HWo) continue;
+        valid |= 1u << j;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int cg = c0 + wc * (BC / WC) + i * 16 + fq * 4;
@@ -204,7 +206,15 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const ConvGemmArgs a) {
                 h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
                 *(bf16x4*)(a.out_bf16 + ob + o) = h;
             }
+            acc[i][j] = v;
         }
+    }
+    if (a.gn_partial) {
+        // GroupNorm statistics of this tile's outputs (requires Cout % BC == 0: every cout column is real)
+        __syncthreads();
+        const int G = a.Cout / a.gn_cpg;
+        float* out = a.gn_partial + (((long long)b * ptiles + (p0 / BP)) * G + c0 / a.gn_cpg) * 3;
+        vt_gn_epilogue_partials<TC, TP>(acc, valid, a.gn_cpg, wp, WP, wc * (BC / WC), BC, (float*)smem, out);
     }
 }
 
@@ -237,6 +247,11 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
     if (a.out_mode == 0 && ((a.ldo % 4) || (a.Cout % 4))) return hipErrorInvalidValue;
     if (a.res && (a.ldr % 4)) return hipErrorInvalidValue;
     if (a.Cin % 8) return hipErrorInvalidValue;                           // k tail handled per 8-element chunk
+    if (a.gn_partial) {
+        if (a.gn_cpg != 4 && a.gn_cpg != 8 && a.gn_cpg != 16) return hipErrorInvalidValue;
+        const int bc = a.Cout <= 32 ? 32 : (a.Cout <= 128 ? 128 : 256);
+        if (a.out_mode != 0 || (a.Cout % bc) || a.Cout <= 32) return hipErrorInvalidValue;
+    }
     // per-image offsets are 32-bit
     if ((long long)a.Hin * a.Win * a.ldx >= (1LL << 31)) return hipErrorInvalidValue;
     if ((long long)a.Wrows * a.ldw >= (1LL << 31)) return hipErrorInvalidValue;
@@ -245,6 +260,11 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
         case 1: return launch_cfg<256, 128, 4, 2>(a, s);
         default: return launch_cfg<256, 256, 2, 4>(a, s);
     }
+}
+
+int vt_conv_gemm_ptiles(int HWo, int Cout) {
+    const int bp = Cout <= 32 ? 128 : 256;
+    return (HWo + bp - 1) / bp;
 }
 
 int vt_conv_gemm_config(const ConvGemmArgs& a) { return a.Cout <= 32 ? 0 : (a.Cout <= 128 ? 1 : 2); }

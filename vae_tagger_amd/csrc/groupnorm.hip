@@ -1,6 +1,7 @@
 // GroupNorm(32, eps) + optional SiLU on NHWC rows -- the HBM-bound half of the encoder
 // (SURVEY.md section 2, K4).  Three launches:
-//   stats    : one read of x  -> per (image, pixel-chunk, group) partial (mean, M2), pivot-shifted fp32
+//   stats    : one read of x  -> per (image, pixel-chunk, group) partial (n, mean, M2), pivot-shifted fp32
+//              (conv epilogues emit the same triples for their outputs, so this pass is only needed for conv_in)
 //   finalize : deterministic fixed-order merge in fp64 -> per (image, channel) (scale, shift)
 //   apply    : y = act(x*scale + shift), one read of x, one bf16 write (the MFMA operand of the next conv)
 // x is the fp32 residual stream or a bf16 conv output.  16-B vector accesses, 8 channels per lane.
@@ -97,34 +98,34 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
             for (int q = 0; q < ppp; ++q)
                 for (int c = 0; c < nct; ++c) chan_merge(n, mean, m2, red[q * tpp + ct0 + c][0][0], red[q * tpp + ct0 + c][0][1], red[q * tpp + ct0 + c][0][2]);
         }
-        float* o = partial + (((long long)b * nchunks + chunk) * groups + g) * 2;
-        o[0] = mean; o[1] = m2;                   // the chunk's element count follows from its geometry
+        float* o = partial + (((long long)b * nchunks + chunk) * groups + g) * 3;
+        o[0] = n; o[1] = mean; o[2] = m2;
     }
 }
 
-// one wave per (image, group): fixed lane<-chunk assignment, fp64 merge, xor-shuffle tree => deterministic
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int HW,
-                                                         int C, int groups, int chunk_pix, float eps,
-                                                         const float* __restrict__ gamma,
+// one wave per (image, group): merges [nparts] (n, mean, M2) triples -- written by gn_stats_kernel or by a
+// conv epilogue -- with a fixed lane<-part assignment, in fp64, then an xor-shuffle tree => deterministic
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nparts, int C,
+                                                         int groups, float eps, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          float* __restrict__ scale_shift) {
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int cpg = C / groups;
-    const float* pb = partial + ((long long)b * nchunks * groups + g) * 2;
-    double s = 0.0;
-    for (int c = lane; c < nchunks; c += 64) {
-        const int pix = min(chunk_pix, HW - c * chunk_pix);
-        s += (double)pix * cpg * (double)pb[(long long)c * groups * 2];
+    const float* pb = partial + ((long long)b * nparts * groups + g) * 3;
+    double n = 0.0, s = 0.0;
+    for (int c = lane; c < nparts; c += 64) {
+        const float* t = pb + (long long)c * groups * 3;
+        n += (double)t[0];
+        s += (double)t[0] * (double)t[1];
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const double n = (double)HW * cpg;
+    for (int o = 32; o > 0; o >>= 1) { n += __shfl_xor(n, o, 64); s += __shfl_xor(s, o, 64); }
     const double mean = s / n;
     double m2 = 0.0;
-    for (int c = lane; c < nchunks; c += 64) {
-        const double mc = pb[(long long)c * groups * 2], m2c = pb[(long long)c * groups * 2 + 1];
-        const int pix = min(chunk_pix, HW - c * chunk_pix);
-        m2 += m2c + (double)pix * cpg * (mc - mean) * (mc - mean);
+    for (int c = lane; c < nparts; c += 64) {
+        const float* t = pb + (long long)c * groups * 3;
+        const double d = (double)t[1] - mean;
+        m2 += (double)t[2] + (double)t[0] * d * d;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
@@ -215,11 +216,11 @@ hipError_t vt_launch_gn_stats(const void* x, int x_is_f32, int B, int HW, int C,
     return hipGetLastError();
 }
 
-hipError_t vt_launch_gn_finalize(const float* partial, int nchunks, int B, int HW, int C, int groups, float eps,
+hipError_t vt_launch_gn_finalize(const float* partial, int nparts, int B, int C, int groups, float eps,
                                  const float* gamma, const float* beta, float* scale_shift, hipStream_t s) {
-    if (!gn_shape_ok(C, groups)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, s, partial, nchunks, HW, C, groups,
-                       chunk_pix_for(HW, C), eps, gamma, beta, scale_shift);
+    if (C <= 0 || groups <= 0 || C % groups || nparts <= 0 || B <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, s, partial, nparts, C, groups, eps, gamma,
+                       beta, scale_shift);
     return hipGetLastError();
 }
 

@@ -8,22 +8,26 @@ namespace {
 // conv_in: x fp32 NCHW [B,3,H,W] (the tensor the reference hands to vae.encode, infer_full.py:98)
 // -> NHWC rows [B][H*W][Cout].  K = 27 is too thin for MFMA and the op is bound by its 128-channel
 // output write, so it is a direct fp32 VALU conv: exact fp32 inputs/weights (no bf16 rounding of the
-// image), 64 pixels x Cout per workgroup, weights + 3-row input halo in LDS.
+// image).  One workgroup = 64 x 16 pixels x Cout: weights (27 x Cout) and the 18-row input halo are
+// staged in LDS once and reused for all 16 rows.  The epilogue also emits GroupNorm (n, mean, M2)
+// partials of the output for the first resnet's norm1.
 // packed weight layout: wp[k][cout], k = ci*9 + ky*3 + kx.
-constexpr int CI_PIX = 64;
+constexpr int CI_PIX = 64, CI_ROWS = 16;
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                       const float* __restrict__ bias, float* __restrict__ o32,
-                                                      bf16_t* __restrict__ o16, int H, int W, int Cout) {
+                                                      bf16_t* __restrict__ o16, float* __restrict__ gn_partial,
+                                                      int gn_cpg, int H, int W, int Cout) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int RW = CI_PIX + 2, RH = CI_ROWS + 2;
     float* sw = sm;                       // [27][Cout]
-    float* sin = sm + 27 * Cout;          // [3 ch][3 rows][CI_PIX + 2]
+    float* sin = sm + 27 * Cout;          // [3 ch][RH rows][RW]
+    float* red = sin + 3 * RH * RW;       // [Cout/4][16][2] stats scratch
     const int tid = threadIdx.x;
-    const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * CI_PIX;
+    const int b = blockIdx.z, y0 = blockIdx.y * CI_ROWS, x0 = blockIdx.x * CI_PIX;
     for (int i = tid; i < 27 * Cout; i += 256) sw[i] = wp[i];
-    constexpr int RW = CI_PIX + 2;
-    for (int i = tid; i < 9 * RW; i += 256) {
-        const int c = i / (3 * RW), r = (i / RW) % 3, xx = i % RW;
-        const int iy = y - 1 + r, ix = x0 - 1 + xx;
+    for (int i = tid; i < 3 * RH * RW; i += 256) {
+        const int c = i / (RH * RW), r = (i / RW) % RH, xx = i % RW;
+        const int iy = y0 - 1 + r, ix = x0 - 1 + xx;
         float v = 0.f;
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long long)b * 3 + c) * H + iy) * W + ix];
         sin[i] = v;
@@ -31,51 +35,86 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     __syncthreads();
     const int cgi = tid & 15, ps = tid >> 4;          // 16 cout-groups of 8, 16 pixel slots of 4
     for (int cg = cgi; cg * 8 < Cout; cg += 16) {
-        float acc[4][8];
-        {
-            const f32x4 b0 = *(const f32x4*)(bias + cg * 8), b1 = *(const f32x4*)(bias + cg * 8 + 4);
+        const f32x4 b0 = *(const f32x4*)(bias + cg * 8), b1 = *(const f32x4*)(bias + cg * 8 + 4);
+        // shifted sums per 4-cout half, pivot = the half's first bias (close to the output mean: E[x] ~ 0)
+        float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;
+        int cnt = 0;
+        for (int row = 0; row < CI_ROWS; ++row) {
+            const int y = y0 + row;
+            if (y >= H) break;
+            float acc[4][8];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 acc[p][0] = b0[0]; acc[p][1] = b0[1]; acc[p][2] = b0[2]; acc[p][3] = b0[3];
                 acc[p][4] = b1[0]; acc[p][5] = b1[1]; acc[p][6] = b1[2]; acc[p][7] = b1[3];
             }
-        }
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                float in6[6];
+                for (int ky = 0; ky < 3; ++ky) {
+                    float in6[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) in6[i] = sin[(c * 3 + ky) * RW + ps * 4 + i];
+                    for (int i = 0; i < 6; ++i) in6[i] = sin[(c * RH + row + ky) * RW + ps * 4 + i];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float* wr = sw + (c * 9 + ky * 3 + kx) * Cout + cg * 8;
-                    const f32x4 w0 = *(const f32x4*)wr, w1 = *(const f32x4*)(wr + 4);
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float* wr = sw + (c * 9 + ky * 3 + kx) * Cout + cg * 8;
+                        const f32x4 w0 = *(const f32x4*)wr, w1 = *(const f32x4*)(wr + 4);
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const float v = in6[p + kx];
-                        acc[p][0] = fmaf(v, w0[0], acc[p][0]); acc[p][1] = fmaf(v, w0[1], acc[p][1]);
-                        acc[p][2] = fmaf(v, w0[2], acc[p][2]); acc[p][3] = fmaf(v, w0[3], acc[p][3]);
-                        acc[p][4] = fmaf(v, w1[0], acc[p][4]); acc[p][5] = fmaf(v, w1[1], acc[p][5]);
-                        acc[p][6] = fmaf(v, w1[2], acc[p][6]); acc[p][7] = fmaf(v, w1[3], acc[p][7]);
+                        for (int p = 0; p < 4; ++p) {
+                            const float v = in6[p + kx];
+                            acc[p][0] = fmaf(v, w0[0], acc[p][0]); acc[p][1] = fmaf(v, w0[1], acc[p][1]);
+                            acc[p][2] = fmaf(v, w0[2], acc[p][2]); acc[p][3] = fmaf(v, w0[3], acc[p][3]);
+                            acc[p][4] = fmaf(v, w1[0], acc[p][4]); acc[p][5] = fmaf(v, w1[1], acc[p][5]);
+                            acc[p][6] = fmaf(v, w1[2], acc[p][6]); acc[p][7] = fmaf(v, w1[3], acc[p][7]);
+                        }
                     }
                 }
-            }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int px = x0 + ps * 4 + p;
-            if (px >= W) continue;
-            const long long o = (((long long)b * H + y) * W + px) * Cout + cg * 8;
-            if (o32) {
-                *(f32x4*)(o32 + o) = f32x4{acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
-                *(f32x4*)(o32 + o + 4) = f32x4{acc[p][4], acc[p][5], acc[p][6], acc[p][7]};
-            }
-            if (o16) {
-                bf16x8 h;
+            for (int p = 0; p < 4; ++p) {
+                const int px = x0 + ps * 4 + p;
+                if (px >= W) continue;
+                const long long o = (((long long)b * H + y) * W + px) * Cout + cg * 8;
+                if (o32) {
+                    *(f32x4*)(o32 + o) = f32x4{acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
+                    *(f32x4*)(o32 + o + 4) = f32x4{acc[p][4], acc[p][5], acc[p][6], acc[p][7]};
+                }
+                if (o16) {
+                    bf16x8 h;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) h[i] = (bf16_t)acc[p][i];
-                *(bf16x8*)(o16 + o) = h;
+                    for (int i = 0; i < 8; ++i) h[i] = (bf16_t)acc[p][i];
+                    *(bf16x8*)(o16 + o) = h;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d0 = acc[p][i] - b0[0], d1 = acc[p][4 + i] - b1[0];
+                    s0 += d0; ss0 = fmaf(d0, d0, ss0); s1 += d1; ss1 = fmaf(d1, d1, ss1);
+                }
+                ++cnt;
             }
+        }
+        if (gn_partial) {
+            // per-thread (n, mean, M2) for each 4-cout half, then fixed-order merges in LDS
+            const float n = 4.0f * (float)cnt;
+            float* r0 = red + ((cg * 2 + 0) * 16 + ps) * 3;
+            float* r1 = red + ((cg * 2 + 1) * 16 + ps) * 3;
+            const float m0 = cnt ? s0 / n : 0.f, m1 = cnt ? s1 / n : 0.f;
+            r0[0] = n; r0[1] = b0[0] + m0; r0[2] = cnt ? fmaxf(ss0 - s0 * m0, 0.f) : 0.f;
+            r1[0] = n; r1[1] = b1[0] + m1; r1[2] = cnt ? fmaxf(ss1 - s1 * m1, 0.f) : 0.f;
+        }
+    }
+    if (gn_partial) {
+        __syncthreads();
+        const int G = Cout / gn_cpg, hpg = gn_cpg >> 2;        // 4-cout halves per group
+        if (tid < G) {
+            float n = 0.f, mean = 0.f, m2 = 0.f;
+            for (int hh = 0; hh < hpg; ++hh)
+                for (int q = 0; q < 16; ++q) {
+                    const float* r = red + ((tid * hpg + hh) * 16 + q) * 3;
+                    vt_chan_merge(n, mean, m2, r[0], r[1], r[2]);
+                }
+            const int part = blockIdx.y * gridDim.x + blockIdx.x, nparts = gridDim.x * gridDim.y;
+            float* o = gn_partial + (((long long)b * nparts + part) * G + tid) * 3;
+            o[0] = n; o[1] = mean; o[2] = m2;
         }
     }
 }
@@ -107,22 +146,84 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int i = tid; i < ldp; i += 256) pr[i] = (bf16_t)(i < n ? __expf(sr[i] - m) * inv : 0.f);
 }
 
+// Single-read variant: the whole row (n <= NV*1024 fp32) lives in registers -- one HBM read, one bf16 write.
+// Requires lds % 4 == 0 and ldp % 4 == 0.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_cached_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
+                                                                  int n, int lds, int ldp) {
+    __shared__ float red[8];
+    const long long row = blockIdx.x;
+    const float* sr = s + row * lds;
+    bf16_t* pr = p + row * ldp;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    f32x4 v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = (k * 256 + tid) * 4;
+        if (i + 3 < n) v[k] = *(const f32x4*)(sr + i);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[k][r] = (i + r < n) ? sr[i + r] : -INFINITY;
+        }
+        m = fmaxf(m, fmaxf(fmaxf(v[k][0], v[k][1]), fmaxf(v[k][2], v[k][3])));
+    }
+    m = wave_max(m);
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[k][r] = __expf(v[k][r] - m); sum += v[k][r]; }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wv] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = (k * 256 + tid) * 4;
+        if (i < ldp) {                      // ldp % 4 == 0: the 4-wide store stays inside the row; pad columns get exp(-inf) = 0
+            bf16x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (bf16_t)(v[k][r] * inv);
+            *(bf16x4*)(pr + i) = h;
+        }
+    }
+}
+
 }  // namespace
 
-hipError_t vt_launch_conv_in(const float* x, const float* wp, const float* bias, float* o32, bf16_t* o16, int B,
-                             int H, int W, int Cout, hipStream_t s) {
+hipError_t vt_launch_conv_in(const float* x, const float* wp, const float* bias, float* o32, bf16_t* o16,
+                             float* gn_partial, int gn_cpg, int* gn_parts, int B, int H, int W, int Cout, hipStream_t s) {
     if (!x || !wp || !bias || (!o32 && !o16) || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 8))
         return hipErrorInvalidValue;
-    const size_t smem = (size_t)(27 * Cout + 9 * (CI_PIX + 2)) * sizeof(float);
+    if (gn_partial && ((gn_cpg % 4) || gn_cpg <= 0 || (Cout % gn_cpg) || Cout / gn_cpg > 256)) return hipErrorInvalidValue;
+    const size_t smem = (size_t)(27 * Cout + 3 * (CI_ROWS + 2) * (CI_PIX + 2) + (Cout / 4) * 16 * 3) * sizeof(float);
     if (smem > 64 * 1024) return hipErrorInvalidValue;
-    dim3 grid((W + CI_PIX - 1) / CI_PIX, H, B);
-    hipLaunchKernelGGL(conv_in_kernel, grid, dim3(256), smem, s, x, wp, bias, o32, o16, H, W, Cout);
+    dim3 grid((W + CI_PIX - 1) / CI_PIX, (H + CI_ROWS - 1) / CI_ROWS, B);
+    if (gn_parts) *gn_parts = grid.x * grid.y;
+    hipLaunchKernelGGL(conv_in_kernel, grid, dim3(256), smem, s, x, wp, bias, o32, o16, gn_partial, gn_cpg, H, W, Cout);
     return hipGetLastError();
 }
+
+int vt_conv_in_parts(int H, int W) { return ((W + CI_PIX - 1) / CI_PIX) * ((H + CI_ROWS - 1) / CI_ROWS); }
 
 hipError_t vt_launch_softmax_rows(const float* scores, bf16_t* probs, int rows, int n, int lds, int ldp,
                                   hipStream_t s) {
     if (!scores || !probs || rows <= 0 || n <= 0 || lds < n || ldp < n) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, scores, probs, n, lds, ldp);
+    const bool vec = (lds % 4 == 0) && (ldp % 4 == 0) && (((uintptr_t)scores) % 16 == 0) && (((uintptr_t)probs) % 8 == 0);
+    const int need = (ldp + 1023) / 1024;           // NV covers ldp so the pad columns are written too
+#define SMX(NV) hipLaunchKernelGGL((softmax_rows_cached_kernel<NV>), dim3(rows), dim3(256), 0, s, scores, probs, n, lds, ldp)
+    if (vec && need <= 1) SMX(1);
+    else if (vec && need <= 2) SMX(2);
+    else if (vec && need <= 4) SMX(4);
+    else if (vec && need <= 8) SMX(8);
+    else if (vec && need <= 16) SMX(16);
+    else hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, scores, probs, n, lds, ldp);
+#undef SMX
     return hipGetLastError();
 }

@@ -38,3 +38,71 @@ __device__ __forceinline__ int vt_xcd_remap(int id, int n) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + slot;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm partial statistics from an MFMA epilogue.
+// A lane holds v[i][j] = 4 consecutive couts (cg .. cg+3, cg = cout_base + i*16 + (lane>>4)*4) of pixel
+// column (lane & 15) for TP pixel rows j; `valid` has bit j set where that pixel exists.
+// Produces one (n, mean, M2) triple per GroupNorm group covered by the workgroup and writes it to
+// out[(group)*3].  Sums are taken relative to a per-(wave, i, fq) pivot (the wave's first pixel), so
+// E[d^2]-E[d]^2 does not cancel when |mean| >> std; merges across lanes / waves use Chan's formula in a
+// fixed order (deterministic).  cpg = channels per group, one of 4, 8, 16.  lds: >= WP*(BC/cpg)*3 floats,
+// free for reuse (callers barrier before).
+__device__ __forceinline__ void vt_chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    if (nb == 0.f) return;
+    const float nn = n + nb, d = mb - mean;
+    mean += d * (nb / nn);
+    m2 += m2b + d * d * (n * nb / nn);
+    n = nn;
+}
+
+template <int TC, int TP>
+__device__ __forceinline__ void vt_gn_epilogue_partials(const f32x4 (&v)[TC][TP], unsigned valid, int cpg, int wp,
+                                                        int nwp, int wave_cout0 /* cout offset of this wave inside the block */,
+                                                        int block_couts, float* lds, float* out /* block's first group */) {
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int gpb = block_couts / cpg;
+    const float nl = 4.0f * (float)__popc(valid);
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const float piv = __shfl(v[i][0][0], lane & 48, 64);
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            if ((valid >> j) & 1u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = v[i][j][r] - piv; s += d; ss = fmaf(d, d, ss); }
+            }
+        }
+        float n = nl;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); n += __shfl_xor(n, o, 64); }
+        float mean = 0.f, m2 = 0.f;
+        if (n > 0.f) { const float ms = s / n; mean = piv + ms; m2 = fmaxf(ss - s * ms, 0.f); }
+        if (cpg >= 8) {
+            const float nb = __shfl_xor(n, 16, 64), mb = __shfl_xor(mean, 16, 64), m2b = __shfl_xor(m2, 16, 64);
+            if ((fq & 1) == 0) vt_chan_merge(n, mean, m2, nb, mb, m2b);
+        }
+        if (cpg >= 16) {
+            const float nb = __shfl_xor(n, 32, 64), mb = __shfl_xor(mean, 32, 64), m2b = __shfl_xor(m2, 32, 64);
+            if (fq == 0) vt_chan_merge(n, mean, m2, nb, mb, m2b);
+        }
+        const int per = cpg >> 2;                      // fq lanes per group
+        if (fr == 0 && (fq % per) == 0) {
+            const int lg = (wave_cout0 + i * 16 + fq * 4) / cpg;
+            float* d = lds + (wp * gpb + lg) * 3;
+            d[0] = n; d[1] = mean; d[2] = m2;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < gpb) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int w = 0; w < nwp; ++w) {
+            const float* d = lds + (w * gpb + threadIdx.x) * 3;
+            vt_chan_merge(n, mean, m2, d[0], d[1], d[2]);
+        }
+        float* o = out + threadIdx.x * 3;
+        o[0] = n; o[1] = mean; o[2] = m2;
+    }
+}

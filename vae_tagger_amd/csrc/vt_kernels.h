@@ -11,7 +11,7 @@ struct ConvGemmArgs {
     float* out_f32;         // optional fp32 output rows [p][ldo]
     bf16_t* out_bf16;       // optional bf16 output rows [p][ldo]
     const void* zeros;      // >= 16 zero bytes in device memory (padding / tail source for the DMA)
-    float* gn_partial;      // optional [batch][ptiles][32][2] (sum, sumsq) of the stored values
+    float* gn_partial;      // optional [batch][ptiles][Cout/gn_cpg][3] (n, mean, M2) of the output values
     int Hin, Win, Hout, Wout;
     int Cin, Cout;             // k per tap; output columns written
     int Wrows;                 // rows of W that exist (rows >= Wrows read as zero)
@@ -42,23 +42,30 @@ struct Conv3x3Args {
     float* out_f32;         // optional
     bf16_t* out_bf16;       // optional
     const void* zeros;
+    float* gn_partial;      // optional [batch][tiles][Cout/gn_cpg][3] (n, mean, M2) of the output values
+    int gn_cpg;             // channels per GroupNorm group of the OUTPUT (4, 8 or 16)
     int batch, H, W, Cin, Cout;
 };
+int vt_conv3x3_halo_tiles(int H, int W, int Cout);
+int vt_conv_gemm_ptiles(int HWo, int Cout);
 bool vt_conv3x3_halo_supported(int Cin, int Cout);
 int vt_conv3x3_halo_config(const Conv3x3Args& a);
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s);
 hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w_ohwi, bf16_t* wp, int Cin, int Cout, hipStream_t s);
 
 // conv_in: fp32 NCHW image -> NHWC 128-channel fp32 (+ optional bf16) rows, direct fp32 conv 3x3 p1.
+// gn_partial (optional): (n, mean, M2) triples of the output, [B][parts][Cout/gn_cpg][3]; *gn_parts receives `parts`.
 hipError_t vt_launch_conv_in(const float* x_nchw, const float* w_packed /*[27][Cout]*/, const float* bias,
-                             float* out_f32, bf16_t* out_bf16, int B, int H, int W, int Cout, hipStream_t s);
+                             float* out_f32, bf16_t* out_bf16, float* gn_partial, int gn_cpg, int* gn_parts, int B, int H,
+                             int W, int Cout, hipStream_t s);
+int vt_conv_in_parts(int H, int W);
 
 // GroupNorm statistics: x rows [B][HW][C] (fp32 or bf16) -> partial (count, mean, M2) per
 // (b, chunk, group), then finalize -> per (b, c) scale/shift so that y = x*scale + shift.
 hipError_t vt_launch_gn_stats(const void* x, int x_is_f32, int B, int HW, int C, int groups,
                               float* partial, int* nchunks_out, hipStream_t s);
-hipError_t vt_launch_gn_finalize(const float* partial, int nchunks, int B, int HW, int C, int groups, float eps,
-                                 const float* gamma, const float* beta, float* scale_shift /*[B][C][2]*/,
+hipError_t vt_launch_gn_finalize(const float* partial /*[B][nparts][groups][3]*/, int nparts, int B, int C, int groups,
+                                 float eps, const float* gamma, const float* beta, float* scale_shift /*[B][C][2]*/,
                                  hipStream_t s);
 int vt_gn_max_chunks(int HW, int C);
 // y = act(x*scale + shift) -> bf16 rows
