@@ -83,6 +83,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         0 = every contraction uses the generic implicit-GEMM kernel (conv_gemm.hip).
  * flag 1: 1 (default) = conv epilogues emit GroupNorm partial statistics for the next norm,
  *         0 = every GroupNorm runs its own statistics pass.
+ * flag 2: 1 = GroupNorm-apply + SiLU in front of a 3x3 stride-1 conv runs inside that conv's halo staging,
+ *         0 (default) = as a standalone HBM-bound pass (one read + one bf16 write of the tensor).
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 
@@ -104,6 +106,11 @@ int vt_profile_end(vt_context* ctx, int max_cfg, long long* launches, double* to
 int vt_op_conv2d(vt_context* ctx, const void* x_bf16_nhwc, const void* w_bf16_ohwi, const float* bias,
                  const float* residual_f32, float* out_f32, void* out_bf16, int B, int Hin, int Win, int Cin,
                  int Cout, int ksize, int stride, int pad_lo, int pad_hi, void* stream);
+/* 3x3 stride-1 pad-1 conv of silu(x*scale + shift): x is fp32 or bf16 NHWC, scale_shift [B][Cin][2]; the
+ * normalise + SiLU runs inside the conv's LDS staging (no separate pass).  Cin % 32 == 0, Cout % 128 == 0. */
+int vt_op_norm_silu_conv3x3(vt_context* ctx, const void* x_nhwc, int x_dtype, const float* scale_shift,
+                            const void* w_bf16_ohwi, const float* bias, const float* residual_f32, float* out_f32,
+                            void* out_bf16, int B, int H, int W, int Cin, int Cout, void* stream);
 /* conv2d whose epilogue also produces the GroupNorm statistics of its output: returns per (image, channel)
  * (scale, shift) with GroupNorm(out) = out*scale + shift.  The encoder uses this fusion between layers. */
 size_t vt_op_conv2d_gn_workspace_bytes(int B, int Hout, int Wout, int Cout);

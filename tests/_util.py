@@ -71,6 +71,21 @@ class Ops:
             outs.append(nchw(o16.float().cpu()))
         return outs[0] if len(outs) == 1 else tuple(outs)
 
+    def norm_silu_conv3x3(self, x_nchw, scale, shift, w_oihw, bias, residual_nchw=None, in_bf16=False):
+        """conv3x3(silu(x*scale[b,c] + shift[b,c])) with the affine+SiLU fused into the conv staging -> fp32 NCHW"""
+        B, Cin, H, W = x_nchw.shape
+        Cout = w_oihw.shape[0]
+        x = nhwc(x_nchw).to(self.dev, torch.bfloat16 if in_bf16 else torch.float32)
+        ss = torch.stack([scale, shift], dim=-1).to(self.dev, torch.float32).contiguous()     # [B, Cin, 2]
+        w = w_oihw.permute(0, 2, 3, 1).contiguous().to(self.dev, torch.bfloat16)
+        b = bias.to(self.dev, torch.float32).contiguous()
+        r = nhwc(residual_nchw).to(self.dev, torch.float32) if residual_nchw is not None else None
+        o32 = torch.full((B, H, W, Cout), float("nan"), device=self.dev, dtype=torch.float32)
+        self.ctx.call("vt_op_norm_silu_conv3x3", vp(x), self.L.VT_BF16 if in_bf16 else self.L.VT_F32, vp(ss), vp(w), vp(b),
+                      vp(r), vp(o32), None, B, H, W, Cin, Cout, self.stream)
+        torch.cuda.synchronize()
+        return nchw(o32.cpu())
+
     def conv2d_gn(self, x_nchw, w_oihw, bias, gamma, beta, residual_nchw=None, stride=1, pad_lo=1, pad_hi=1, groups=32, eps=1e-6):
         """-> (conv output fp32 NCHW, scale_shift [B,Cout,2]) with the statistics taken in the conv epilogue."""
         B, Cin, H, W = x_nchw.shape

@@ -73,6 +73,29 @@ def test_conv2d_identity_weights_asymmetric_input(ops, conv_kernel):
         assert torch.equal(got, ref), f"tap {tap}"
 
 
+FUSED_CASES = [(2, 128, 128, 40, 50), (1, 128, 256, 33, 17), (1, 256, 256, 20, 36), (1, 512, 512, 16, 16), (2, 256, 128, 7, 5),
+               (1, 32, 128, 9, 9), (1, 64, 256, 18, 18)]
+
+
+@pytest.mark.parametrize("in_bf16", [False, True])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", FUSED_CASES)
+def test_fused_norm_silu_conv3x3(ops, B, Cin, Cout, H, W, in_bf16):
+    """GroupNorm-apply + SiLU inside the conv's halo staging == conv(bf16(silu(x*scale+shift)))."""
+    x = _rand((B, Cin, H, W), 31) * 1.5 + 0.3
+    if in_bf16:
+        x = bf16_round(x)
+    scale = 0.5 + torch.rand(B, Cin, generator=torch.Generator().manual_seed(32))
+    shift = _rand((B, Cin), 33, 0.5)
+    w = bf16_round(_rand((Cout, Cin, 3, 3), 34, (Cin * 9) ** -0.5))
+    b = _rand((Cout,), 35, 0.1)
+    res = _rand((B, Cout, H, W), 36)
+    a = bf16_round(F.silu(x * scale.view(B, Cin, 1, 1) + shift.view(B, Cin, 1, 1)))
+    ref = F.conv2d(a, w, b, padding=1) + res
+    got = ops.norm_silu_conv3x3(x, scale, shift, w, b, residual_nchw=res, in_bf16=in_bf16)
+    # the device SiLU (v_exp + v_rcp) can round a bf16 operand the other way now and then: bf16-level tolerance
+    assert torch.allclose(got, ref, rtol=2e-3, atol=4e-3), (got - ref).abs().max()
+
+
 GN_EPI_CASES = [(2, 128, 128, 40, 50, 3, 1, 1, 1), (1, 128, 256, 33, 17, 3, 1, 1, 1), (1, 256, 512, 20, 20, 3, 1, 1, 1),
                 (2, 128, 128, 17, 22, 3, 2, 0, 1), (1, 256, 512, 12, 20, 1, 1, 0, 0)]
 

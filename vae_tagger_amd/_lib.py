@@ -39,6 +39,7 @@ PROTOTYPES = {
     "vt_profile_begin": (_i, [_vp]),
     "vt_profile_end": (_i, [_vp, _i, _c.POINTER(_ll), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_char_p)]),
     "vt_op_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vt_op_norm_silu_conv3x3": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vt_op_conv2d_gn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vt_op_conv2d_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "vt_op_gemm_nt": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _f, _i, _vp]),

@@ -78,6 +78,7 @@ struct vt_context {
     bool dec_configured = false, dec_finalized = false;
     int use_halo_conv = 1;          // vt_set_flag(ctx, 0, v)
     int fuse_gn_stats = 1;          // vt_set_flag(ctx, 1, v)
+    int fuse_gn_apply = 0;          // vt_set_flag(ctx, 2, v): break-even on MI355X today, off by default
     void* op_scratch = nullptr; size_t op_scratch_bytes = 0;
 
     // optional per-launch timing of the MFMA kernel (HIP events on the launch stream)
@@ -237,19 +238,24 @@ int run_gn(vt_context* c, const void* x, int is_f32, int B, int HW, const NormW&
 }
 
 // `gn`: if non-null, the epilogue also writes GroupNorm partials of the output (cpg = cout / groups)
+// `xnorm_f32` / `ss`: when ss is given the conv input is silu(x*scale + shift) with x = xnorm_f32 (fp32) or x (bf16),
+// fused into the halo staging (only valid when norm_conv_fusable()).
 int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int Win, int stride, int pad, int Hout,
-             int Wout, const float* res, float* o32, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32) {
+             int Wout, const float* res, float* o32, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32,
+             const float* xnorm_f32 = nullptr, const float* ss = nullptr) {
     const int cpg = w.cout / groups;
     const bool fuse = gn && c->fuse_gn_stats && (cpg == 4 || cpg == 8 || cpg == 16);
     if (gn) gn->parts = 0;
     if (c->use_halo_conv && w.wp && w.k == 3 && stride == 1 && pad == 1 && Hout == Hin && Wout == Win) {
         Conv3x3Args h{};
-        h.X = x; h.Wp = w.wp; h.bias = w.b; h.res = res; h.out_f32 = o32; h.out_bf16 = o16; h.zeros = c->zeros;
+        h.X = xnorm_f32 ? nullptr : x; h.Xf32 = xnorm_f32; h.scale_shift = ss;
+        h.Wp = w.wp; h.bias = w.b; h.res = res; h.out_f32 = o32; h.out_bf16 = o16; h.zeros = c->zeros;
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout); }
         HIPCK(c, launch_halo(c, h, s), "conv3x3_halo");
         return VT_OK;
     }
+    if (ss) return c->fail(VT_ERR_STATE, "internal: fused norm requested for a conv the halo kernel cannot run");
     ConvGemmArgs a{};
     a.X = x; a.W = w.w; a.bias = w.b; a.res = res; a.out_f32 = o32; a.out_bf16 = o16; a.zeros = c->zeros;
     a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cin = w.cin; a.Cout = w.cout; a.Wrows = w.cout;
@@ -262,6 +268,30 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     }
     HIPCK(c, launch_gemm(c, a, s), "conv_gemm");
     return VT_OK;
+}
+
+bool norm_conv_fusable(const vt_context* c, const ConvW& w, int cin) {
+    return c->fuse_gn_apply && c->use_halo_conv && w.wp && w.k == 3 && cin * 8 <= 8192;
+}
+
+// conv3x3(silu(GroupNorm(x))) with x fp32 (x32) or bf16 (x16).  Statistics come from the producer's epilogue
+// when available (gn.parts > 0); the normalise+SiLU runs inside the conv's halo staging when the halo kernel
+// applies, otherwise as the standalone pass into `act`.
+int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const float* x32, const bf16_t* x16, int B, int H, int W,
+                  int groups, bf16_t* act, const float* res, float* o32, bf16_t* o16, GnState& gn, bool want_stats,
+                  hipStream_t s) {
+    const void* x = x32 ? (const void*)x32 : (const void*)x16;
+    const int is_f32 = x32 != nullptr;
+    if (!norm_conv_fusable(c, w, n.c)) {
+        int r = run_gn(c, x, is_f32, B, H * W, n, groups, 1, act, gn, s);
+        if (r) return r;
+        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, o32, o16, s, want_stats ? &gn : nullptr, groups);
+    }
+    int parts = gn.parts;
+    if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, is_f32, B, H * W, n.c, groups, gn.partial, &parts, s), "gn_stats");
+    gn.parts = 0;
+    HIPCK(c, vt_launch_gn_finalize(gn.partial, parts, B, n.c, groups, 1e-6f, n.g, n.b, gn.ss, s), "gn_finalize");
+    return run_conv(c, w, x16, B, H, W, 1, 1, H, W, res, o32, o16, s, want_stats ? &gn : nullptr, groups, x32, gn.ss);
 }
 
 struct AttnScratch { bf16_t* qk; bf16_t* vt; float* scores; bf16_t* probs; bf16_t* o; };
@@ -570,14 +600,12 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             if ((rr = run_conv(c, rw.sc, h16_for_shortcut, B, h, w, 1, 0, h, w, nullptr, f32[scb], nullptr, s))) return rr;
             res = f32[scb];
         }
-        if ((rr = run_gn(c, f32[cur], 1, B, h * w, rw.n1, e.groups, 1, act, gn, s))) return rr;
-        if ((rr = run_conv(c, rw.c1, act, B, h, w, 1, 1, h, w, nullptr, nullptr, tmid, s, &gn, e.groups))) return rr;
-        if ((rr = run_gn(c, tmid, 0, B, h * w, rw.n2, e.groups, 1, act, gn, s))) return rr;
+        if ((rr = run_norm_conv(c, rw.n1, rw.c1, f32[cur], nullptr, B, h, w, e.groups, act, nullptr, nullptr, tmid, gn, true, s))) return rr;
         if (want_bf16_out) {
             // the only consumer is the downsample conv (bf16 operand, no norm): skip the fp32 copy of h and the stats
-            return run_conv(c, rw.c2, act, B, h, w, 1, 1, h, w, res, nullptr, hb, s);
+            return run_norm_conv(c, rw.n2, rw.c2, nullptr, tmid, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s);
         }
-        if ((rr = run_conv(c, rw.c2, act, B, h, w, 1, 1, h, w, res, f32[nxt], nullptr, s, &gn, e.groups))) return rr;
+        if ((rr = run_norm_conv(c, rw.n2, rw.c2, nullptr, tmid, B, h, w, e.groups, act, res, f32[nxt], nullptr, gn, true, s))) return rr;
         cur = nxt;
         return VT_OK;
     };
@@ -781,6 +809,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (!c) return VT_ERR_INVALID;
     if (flag == 0) { c->use_halo_conv = value != 0; return VT_OK; }
     if (flag == 1) { c->fuse_gn_stats = value != 0; return VT_OK; }
+    if (flag == 2) { c->fuse_gn_apply = value != 0; return VT_OK; }
     return c->fail(VT_ERR_INVALID, "vt_set_flag: unknown flag %d", flag);
 }
 
@@ -839,6 +868,31 @@ int vt_op_conv2d(vt_context* c, const void* x, const void* w, const float* bias,
     a.x_bs = (long long)Hin * Win * Cin; a.o_bs = (long long)Hout * Wout * Cout; a.r_bs = a.o_bs; a.batch = B;
     a.alpha = 1.f; a.bias_mode = bias ? 1 : 0;
     HIPCK(c, launch_gemm(c, a, (hipStream_t)stream), "vt_op_conv2d");
+    return VT_OK;
+}
+
+// conv3x3(silu(x*scale + shift)), stride 1, pad 1, with the affine + SiLU fused into the conv's halo staging
+int vt_op_norm_silu_conv3x3(vt_context* c, const void* x, int x_dtype, const float* scale_shift, const void* w,
+                            const float* bias, const float* res, float* o32, void* o16, int B, int H, int W, int Cin,
+                            int Cout, void* stream) {
+    if (!c) return VT_ERR_INVALID;
+    if (!x || !scale_shift || !w || (!o32 && !o16)) return c->fail(VT_ERR_INVALID, "vt_op_norm_silu_conv3x3: null buffer");
+    if (x_dtype != VT_F32 && x_dtype != VT_BF16) return c->fail(VT_ERR_INVALID, "vt_op_norm_silu_conv3x3: x must be f32 or bf16");
+    if (!vt_conv3x3_halo_supported(Cin, Cout) || Cin * 8 > 8192) return c->fail(VT_ERR_INVALID, "vt_op_norm_silu_conv3x3: unsupported channel counts %d -> %d", Cin, Cout);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = (size_t)Cout * 9 * Cin * 2;
+    if (c->op_scratch_bytes < need) {
+        if (c->op_scratch) (void)hipFree(c->op_scratch);
+        c->op_scratch = nullptr; c->op_scratch_bytes = 0;
+        HIPCK(c, hipMalloc(&c->op_scratch, need), "hipMalloc(op scratch)");
+        c->op_scratch_bytes = need;
+    }
+    HIPCK(c, vt_launch_repack_ohwi_to_halo((const bf16_t*)w, (bf16_t*)c->op_scratch, Cin, Cout, s), "repack");
+    Conv3x3Args h{};
+    h.X = x_dtype == VT_BF16 ? (const bf16_t*)x : nullptr; h.Xf32 = x_dtype == VT_F32 ? (const float*)x : nullptr;
+    h.scale_shift = scale_shift; h.Wp = (const bf16_t*)c->op_scratch; h.bias = bias; h.res = res; h.out_f32 = o32;
+    h.out_bf16 = (bf16_t*)o16; h.zeros = c->zeros; h.batch = B; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout;
+    HIPCK(c, launch_halo(c, h, s), "vt_op_norm_silu_conv3x3");
     return VT_OK;
 }
 

@@ -38,26 +38,66 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
     }
 }
 
-template <int WP, int WC>
+// s_waitcnt vmcnt(n) that also names the registers an inline-asm load wrote: nothing that consumes them
+// can be scheduled above the wait (hipcc neither counts asm loads nor knows when their data lands).
+template <typename V>
+__device__ __forceinline__ void wait_vmcnt_tied(int n, V& r0, V& r1) {
+    switch (n) {
+#define C(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" : "+v"(r0), "+v"(r1)::"memory"); break;
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16)
+#undef C
+        default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)::"memory"); break;
+    }
+}
+
+// Identity the optimiser cannot see through: stops loop-invariant address arithmetic built on `v` from being
+// hoisted into (and spilled from) long-lived registers -- it is recomputed where it is used instead.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <typename V>
+__device__ __forceinline__ void wait_vmcnt_tied1(int n, V& r0) {
+    switch (n) {
+#define C(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" : "+v"(r0)::"memory"); break;
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16)
+#undef C
+        default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0)::"memory"); break;
+    }
+}
+
+// XT selects how the X halo reaches LDS:
+//   0  bf16 activations, copied as they are by LDS-DMA;
+//   1  fp32 tensor (the residual stream), 2  bf16 tensor (a conv1 output): loaded to registers by
+//      hand-counted inline-asm global loads, GroupNorm'ed with the per-(image, channel) (scale, shift) the
+//      previous layer's epilogue statistics produced, SiLU'ed, rounded to bf16 and written to LDS -- the
+//      standalone GroupNorm+SiLU pass (one read + one write of the whole tensor) disappears.
+template <int WP, int WC, int XT>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) {
     static_assert(WP * WC == 8, "8 waves");
     constexpr int ROWS = WP * 8;                 // tile rows (each wave: 8 rows x 16 px)
     constexpr int BC = WC * 64;                  // couts per workgroup (each wave: 64)
     constexpr int TP = 8, TC = 4;
     constexpr int HROWS = (ROWS + 2) * HWID;     // halo pixels
-    constexpr int NXW = (HROWS + 127) / 128;     // X DMA wave-instructions per wave (16 rows each, 8 waves)
+    constexpr int NXW = (HROWS + 127) / 128;     // X staging wave-instructions per wave (16 rows each, 8 waves)
     constexpr int XBUF = NXW * 128 * HB;         // bytes per X halo buffer
     constexpr int WPW = BC / 128;                // W DMA wave-instructions per wave per K-step
     constexpr int WBUF = BC * HB;                // bytes per W stage
+    constexpr int LX = XT == 1 ? 2 : 1;          // register loads per staged row (8 channels)
+    constexpr int DLY = XT == 1 ? 2 : 3;         // K-steps between a row's load and its normalise+write
     static_assert(WPW >= 1, "BC >= 128");
+    static_assert(XT == 0 || NXW + DLY <= 9, "staging must finish inside the chunk");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xbase = smem;                    // 2 halo buffers
     char* const wbase = smem + 2 * XBUF;         // NW weight stages
+    float* const ssl = (float*)(wbase + NW * WBUF);   // XT != 0: (scale, shift) per input channel
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wp = wave / WC, wc = wave % WC;
+    const bool early = wave < 4;                 // staging phase of this wave (see the K-loop)
 
     // ---- tile coordinates
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + ROWS - 1) / ROWS;
@@ -71,11 +111,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     const int ty0 = (tile / tiles_x) * ROWS, tx0 = (tile % tiles_x) * TW;
     const int c0 = ct * BC;
 
-    const bf16_t* Xb = a.X + (long long)b * a.H * a.W * a.Cin;
+    const long long img = (long long)b * a.H * a.W * a.Cin;
+    const bf16_t* Xb = a.X ? a.X + img : nullptr;
+    const float* Xf = a.Xf32 ? a.Xf32 + img : nullptr;
     const int nchunk = a.Cin >> 5;
     const int nk = nchunk * 9;
 
-    // ---- DMA bookkeeping.  One wave-instruction = 16 LDS rows x 64 B; lane l -> row (l >> 2), physical
+    // ---- staging bookkeeping.  One wave-instruction = 16 LDS rows x 64 B; lane l -> row (l >> 2), physical
     // chunk (l & 3); logical chunk = physical ^ swz(row), swz(row) = ((row >> 2) & 1) << 1 = ((l >> 4) & 1) << 1.
     const int drow = lane >> 2;
     const int dchunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
@@ -94,7 +136,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     for (int j = 0; j < WPW; ++j) wsrc[j] = (c0 + (j * 8 + wave) * 16 + drow) * 32 + dchunk * 8;
     const int wstep = a.Cout * 32;               // elements between consecutive K-steps
 
-    auto issue_x = [&](int chunk) {
+    auto issue_x_dma = [&](int chunk) {          // XT == 0
         char* dst = xbase + (chunk & 1) * XBUF;
 #pragma unroll
         for (int j = 0; j < NXW; ++j) {
@@ -108,6 +150,49 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
             __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(wt + wsrc[j]), VT_LDS_PTR(dst + (j * 8 + wave) * 1024), 16, 0, 0);
+    };
+    // register-staged row: 8 channels of one halo pixel (XT 1: 2 x 16 B of fp32, XT 2: 16 B of bf16)
+    auto load_row = [&](int j, int chunk, f32x4& r0, f32x4& r1) {
+        const int xs_j = opaque(xsrc[j]);
+        const int off = xs_j >= 0 ? xs_j + chunk * 32 : 0;
+        if constexpr (XT == 1) {
+            const float* src = xs_j >= 0 ? Xf + off : (const float*)a.zeros;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r0) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r1) : "v"(src) : "memory");
+        } else {
+            const bf16_t* src = xs_j >= 0 ? Xb + off : (const bf16_t*)a.zeros;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r0) : "v"(src) : "memory");
+        }
+    };
+    // y = silu(x * scale + shift) -> bf16, written where the DMA would have put the raw row
+    auto write_row = [&](int j, int chunk, const f32x4& r0, const f32x4& r1) {
+        const float* sp = ssl + (chunk * 32 + opaque(dchunk) * 8) * 2;
+        char* dst = xbase + (chunk & 1) * XBUF + (j * 8 + wave) * 1024 + opaque(lane) * 16;
+        const bool pad = xsrc[j] < 0;                              // conv zero padding applies AFTER norm + SiLU
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float v[4];
+            if constexpr (XT == 1) {
+                const f32x4 r = hh ? r1 : r0;
+                v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
+            } else {
+                const bf16x8 h = __builtin_bit_cast(bf16x8, r0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (float)h[hh * 4 + i];
+            }
+            const f32x4 q0 = *(const f32x4*)(sp + hh * 8), q1 = *(const f32x4*)(sp + hh * 8 + 4);   // (scale, shift) x 4 ch
+            bf16x4 o;
+#ifdef EXP_NOMATH
+            o[0] = (bf16_t)(v[0] + q0[0]); o[1] = (bf16_t)(v[1] + q0[2]); o[2] = (bf16_t)(v[2] + q1[0]); o[3] = (bf16_t)(v[3] + q1[2]);
+#else
+            o[0] = (bf16_t)vt_silu(fmaf(v[0], q0[0], q0[1]));
+            o[1] = (bf16_t)vt_silu(fmaf(v[1], q0[2], q0[3]));
+            o[2] = (bf16_t)vt_silu(fmaf(v[2], q1[0], q1[1]));
+            o[3] = (bf16_t)vt_silu(fmaf(v[3], q1[2], q1[3]));
+#endif
+            if (pad) o = bf16x4{0, 0, 0, 0};
+            *(bf16x4*)(dst + hh * 8) = o;
+        }
     };
 
     // ---- fragment addressing
@@ -129,56 +214,109 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
         for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: X(0), then W(0..NW-2)
-    issue_x(0);
+    if constexpr (XT == 0) {
+        issue_x_dma(0);
+    } else {
+        const float* ssg = a.scale_shift + (long long)b * a.Cin * 2;
+        for (int i = threadIdx.x; i < a.Cin * 2; i += 512) ssl[i] = ssg[i];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NXW; ++j) {
+            f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
+            load_row(j, 0, r0, r1);
+            if constexpr (XT == 1) wait_vmcnt_tied(0, r0, r1);
+            else wait_vmcnt_tied1(0, r0);
+            write_row(j, 0, r0, r1);
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NW - 1; ++t)
         if (t < nk) issue_w(t);
 
     // One chunk = 9 K-steps (taps).  LAST = the final chunk: no next halo, weight ring drains, so the
-    // wait count is computed at run time; every other chunk uses compile-time s_waitcnt immediates.
+    // wait count is computed at run time; every other chunk's counts fold to immediates after unrolling.
+    // VM-op issue order per wave and step: [wait][barrier] W(t+NW-1) [then, XT != 0 and tap < NXW: row `tap` of
+    // the next chunk's halo].  All VM ops retire in order, so "at most N outstanding" with N = number of ops
+    // ISSUED after op X  <=>  X has landed.
     auto do_chunk = [&](int chunk, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const char* xs = xbase + (chunk & 1) * XBUF;
         const int tbase = chunk * 9;
+        f32x4 rq[DLY][XT == 1 ? 2 : 1];           // staged rows in flight (static indices after unrolling)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int t = tbase + tap;
-            // younger-than-W(t) DMA ops of this wave: W(t+1 .. t+NW-2) and, for taps 1..NW-1, the next
-            // chunk's halo (issued at tap 0).  Everything older -- W(t) and this chunk's halo -- has
-            // landed once vmcnt <= that count (VM ops retire in order).
             if constexpr (!LAST) {
-                constexpr int n_in = (NW - 2) * WPW + NXW, n_out = (NW - 2) * WPW;
-                if (tap >= 1 && tap <= NW - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_in) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_out) : "memory");
+                int n = (NW - 2) * WPW;           // W(t+1 .. t+NW-2)
+                if (XT == 0) { if (tap >= 1 && tap <= NW - 1) n += NXW; }                 // next halo, DMA'd at tap 0
+                else { for (int r = tap - (NW - 1); r <= tap - 1; ++r) if (r >= 0 && r < NXW) n += LX; }
+                wait_vmcnt(n);
             } else {
                 int ahead = nk - 1 - t;
                 if (ahead > NW - 2) ahead = NW - 2;
                 wait_vmcnt(ahead * WPW);
             }
+            if (XT != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's staged rows are written
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();        // all waves' pieces of W(t) (and X(chunk)) are in LDS;
             asm volatile("" ::: "memory");       // everyone is done reading stage (t-1) % NW
             if (!LAST || t + NW - 1 < nk) issue_w(t + NW - 1);
-            if (!LAST && tap == 0) issue_x(chunk + 1);
+            if constexpr (!LAST && XT == 0) { if (tap == 0) issue_x_dma(chunk + 1); }
 
-            const char* ws = wbase + (t % NW) * WBUF + wfoff;
+            const char* ws = wbase + (t % NW) * WBUF + opaque(wfoff);     // stage bases beyond 64 KB cannot be ds_read immediates
             const int dy = tap / 3, dx = tap % 3;
-            bf16x8 wf[TC], xf[TP];
+            bf16x8 wf[TC];
 #pragma unroll
             for (int i = 0; i < TC; ++i) wf[i] = *(const bf16x8*)(ws + i * 16 * HB);
-#pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                constexpr int dummy = 0; (void)dummy;
-                const int rel = (j + dy) * HWID + dx;                 // compile-time after unrolling
-                xf[j] = *(const bf16x8*)(xs + xsel[rel & 7] + rel * HB);
+
+            // XT != 0: the row loaded DLY steps ago is normalised + SiLU'ed + written to LDS during THIS step.
+            // Both waves of a SIMD leave the barrier together, so if both did this VALU work at the same point the
+            // matrix pipe would idle meanwhile.  Waves w and w+4 share a SIMD: the first half of the workgroup
+            // stages BEFORE its MFMAs, the second half AFTER, so each wave's VALU work runs beside its partner's MFMAs.
+            constexpr bool STAGE = !LAST && XT != 0;
+            const int r = tap - DLY;
+            auto stage_row = [&]() {
+                int n = DLY * WPW;                // W issued in steps r+1 .. tap (this step's W is already out)
+                for (int q = r + 1; q < tap; ++q) if (q < NXW) n += LX;          // rows r+1 .. tap-1
+#ifndef EXP_NOWAIT
+                if constexpr (XT == 1) wait_vmcnt_tied(n, rq[r % DLY][0], rq[r % DLY][1]);
+                else wait_vmcnt_tied1(n, rq[r % DLY][0]);
+#endif
+                write_row(r, chunk + 1, rq[r % DLY][0], rq[r % DLY][XT == 1 ? 1 : 0]);
+            };
+            if constexpr (STAGE) {
+                if (r >= 0 && r < NXW) {
+                    if (early) stage_row();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < TC; ++i)
+            for (int jh = 0; jh < TP; jh += 4) {                          // two halves: 16 live X-fragment registers
+                bf16x8 xf[4];
 #pragma unroll
-                for (int j = 0; j < TP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const int rel = (jh + j + dy) * HWID + dx;            // compile-time after unrolling
+                    xf[j] = *(const bf16x8*)(xs + xsel[rel & 7] + rel * HB);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < TC; ++i)
+                        acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][jh + j], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
+            if constexpr (STAGE) {
+                if (r >= 0 && r < NXW) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!early) stage_row();
+                }
+                // load row `tap` of the next chunk into the slot just freed.  VM issue order stays
+                // W(t+NW-1) -> row `tap` -> W(t+NW).
+#ifndef EXP_NOLOAD
+                if (tap < NXW) load_row(tap, chunk + 1, rq[tap % DLY][0], rq[tap % DLY][XT == 1 ? 1 : 0]);
+#endif
+            }
         }
     };
     for (int chunk = 0; chunk + 1 < nchunk; ++chunk) do_chunk(chunk, std::false_type{});
@@ -220,17 +358,17 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     }
 }
 
-template <int WP, int WC>
+template <int WP, int WC, int XT>
 hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
     constexpr int ROWS = WP * 8, BC = WC * 64;
     constexpr int HROWS = (ROWS + 2) * HWID;
     constexpr int NXW = (HROWS + 127) / 128;
-    constexpr int smem = 2 * NXW * 128 * HB + NW * BC * HB;
-    static_assert(smem <= 160 * 1024, "LDS budget");
+    const int smem = 2 * NXW * 128 * HB + NW * BC * HB + (XT ? a.Cin * 8 : 0);
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
-    auto kern = conv3x3_halo_kernel<WP, WC>;
+    auto kern = conv3x3_halo_kernel<WP, WC, XT>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -270,11 +408,16 @@ bool vt_conv3x3_halo_supported(int Cin, int Cout) { return Cin >= 32 && (Cin % 3
 int vt_conv3x3_halo_config(const Conv3x3Args& a) { return (a.Cout % 256) == 0 ? 4 : 3; }   // profile slots 3, 4
 
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
-    if (!a.X || !a.Wp || !a.zeros || (!a.out_f32 && !a.out_bf16)) return hipErrorInvalidValue;
+    if (!a.Wp || !a.zeros || (!a.out_f32 && !a.out_bf16)) return hipErrorInvalidValue;
     if (!vt_conv3x3_halo_supported(a.Cin, a.Cout) || a.batch <= 0 || a.H <= 0 || a.W <= 0) return hipErrorInvalidValue;
     if (a.gn_partial && a.gn_cpg != 4 && a.gn_cpg != 8 && a.gn_cpg != 16) return hipErrorInvalidValue;
     if ((long long)a.H * a.W * a.Cin >= (1LL << 31)) return hipErrorInvalidValue;        // 32-bit per-image offsets
     if ((long long)(a.Cin / 32) * 9 * a.Cout * 32 >= (1LL << 31)) return hipErrorInvalidValue;
-    if ((a.Cout % 256) == 0) return launch<2, 4>(a, s);     // 16x16 px x 256 couts
-    return launch<4, 2>(a, s);                              // 32x16 px x 128 couts
+    // input mode: raw bf16 (X), or GroupNorm+SiLU fused into the staging of an fp32 (Xf32) / bf16 (X) tensor
+    const int xt = a.scale_shift ? (a.Xf32 ? 1 : 2) : 0;
+    if (xt == 1 ? (a.X != nullptr) : (a.X == nullptr || a.Xf32 != nullptr)) return hipErrorInvalidValue;
+    const bool big = (a.Cout % 256) == 0;                   // 16x16 px x 256 couts, else 32x16 px x 128 couts
+    if (xt == 0) return big ? launch<2, 4, 0>(a, s) : launch<4, 2, 0>(a, s);
+    if (xt == 1) return big ? launch<2, 4, 1>(a, s) : launch<4, 2, 1>(a, s);
+    return big ? launch<2, 4, 2>(a, s) : launch<4, 2, 2>(a, s);
 }

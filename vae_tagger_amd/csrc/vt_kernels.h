@@ -35,7 +35,9 @@ constexpr int VT_NUM_MFMA_CONFIGS = 5;   // 0..2 conv_gemm tiles, 3..4 conv3x3_h
 
 // 3x3 stride-1 pad-1 conv, halo-tile kernel (conv3x3_halo.hip)
 struct Conv3x3Args {
-    const bf16_t* X;        // NHWC bf16 [batch][H][W][Cin]
+    const bf16_t* X;        // NHWC bf16 [batch][H][W][Cin]          (exactly one of X / Xf32)
+    const float* Xf32;      // NHWC fp32 [batch][H][W][Cin]: only with scale_shift
+    const float* scale_shift;  // optional [batch][Cin][2]: the input is silu(x*scale + shift), fused into staging
     const bf16_t* Wp;       // packed [Cin/32][9][Cout][32] bf16
     const float* bias;      // [Cout] or null
     const float* res;       // optional fp32 residual [batch][H][W][Cout]
