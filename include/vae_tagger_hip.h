@@ -92,7 +92,9 @@ int vt_set_flag(vt_context* ctx, int flag, int value);
  * Between vt_profile_begin and vt_profile_end every launch of the implicit-GEMM MFMA kernel is
  * bracketed by hipEvents recorded on the launch stream.  vt_profile_end synchronises on them and
  * returns, per kernel/tile configuration (vt_profile_num_configs() of them), the launch count, summed duration (ms) and summed
- * ALGORITHMIC FLOPs (2*B*Hout*Wout*Cout*taps*Cin).  bench.py derives roofline.achieved from these.
+ * ALGORITHMIC FLOPs (2*B*Hout*Wout*Cout*taps*Cin).  The LAST slot is the HBM-bound GroupNorm(+SiLU) apply
+ * pass: its 'flops' entry carries algorithmic BYTES (one read + one bf16 write).  bench.py derives
+ * roofline.achieved from these.
  */
 int vt_profile_num_configs(void);
 int vt_profile_begin(vt_context* ctx);

@@ -1,0 +1,87 @@
+"""CLI counterparts of infer_full.py / infer_vae.py: flag surface (CPU) and end-to-end run on MI355X (GPU)."""
+import json
+
+import pytest
+import torch
+
+from vae_tagger_amd import infer_full, infer_vae, synth
+
+REF_FULL_FLAGS = {  # reference infer_full.py:143-180
+    "--vae_checkpoint", "--vae_config_path", "--decoder_checkpoint", "--image_path", "--tags_csv_path", "--output_dir",
+    "--resolution", "--confidence_threshold", "--use_attention", "--no_attention", "--use_spatial_attention",
+    "--use_self_attention", "--use_cross_attention", "--attention_heads", "--attention_dropout", "--model_checkpoint"}
+REF_VAE_FLAGS = {"--vae_checkpoint", "--vae_config_path", "--image_path", "--output_dir", "--resolution"}   # infer_vae.py:83-91
+
+
+def _flags(parser):
+    return {o for a in parser._actions for o in a.option_strings if o.startswith("--") and o != "--help"}
+
+
+def test_cli_flags_match_reference():
+    assert REF_FULL_FLAGS <= _flags(infer_full.build_parser())
+    assert _flags(infer_full.build_parser()) - REF_FULL_FLAGS == {"--batch_size"}
+    assert _flags(infer_vae.build_parser()) - REF_VAE_FLAGS == {"--batch_size"}
+    a = infer_full.build_parser().parse_args(["--vae_checkpoint", "v", "--decoder_checkpoint", "d", "--image_path", "i",
+                                              "--tags_csv_path", "t"])
+    assert (a.resolution, a.confidence_threshold, a.output_dir, a.use_attention, a.use_cross_attention) == \
+        (1024, 0.5, "inference_output", True, False)
+
+
+def test_summarize_matches_reference_schema():
+    conf = [0.98765, 0.7, 0.50004, 0.49, 0.1, 0.05]
+    idx = [3, 0, 5, 1, 2, 4]
+    tags = [f"t{i}" for i in range(6)]
+    r = infer_full.summarize(conf, idx, tags, 0.5)
+    assert r["predicted_tags"] == [{"tag": "t3", "confidence": 0.9877}, {"tag": "t0", "confidence": 0.7},
+                                   {"tag": "t5", "confidence": 0.5}]
+    assert r["total_tags_above_threshold"] == 3 and r["max_confidence"] == 0.9877
+    assert r["avg_confidence_top5"] == float(f"{sum(conf[:5]) / 5:.4f}")
+    short = infer_full.summarize([0.9, 0.2], [1, 0], tags, 0.5)          # fewer than 5 tags: still divides by 5
+    assert short["avg_confidence_top5"] == float(f"{(0.9 + 0.2) / 5:.4f}")
+
+
+@pytest.mark.gpu
+def test_infer_full_and_infer_vae_end_to_end(tmp_path):
+    from PIL import Image
+    from safetensors.torch import save_file
+    from oracle import decoder_ref, encoder_ref
+    from vae_tagger_amd.modules import get_image_transform
+    n_tags, res = 40, 128
+    g = torch.Generator().manual_seed(5)
+    imgs = tmp_path / "imgs"
+    imgs.mkdir()
+    for i, size in enumerate([(200, 150), (128, 128), (90, 160)]):
+        arr = (torch.rand(size[1], size[0], 3, generator=g) * 255).to(torch.uint8).numpy()
+        Image.fromarray(arr).save(imgs / f"img{i}.png")
+    (imgs / "broken.png").write_bytes(b"not a png")                        # skip-and-count
+    sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    sd_e["decoder.conv_in.weight"] = torch.zeros(4)                       # real checkpoints carry decoder.* keys too
+    save_file(sd_e, str(tmp_path / "vae.safetensors"))
+    sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(n_tags), seed=1)
+    torch.save(sd_d, tmp_path / "dec.pth")
+    (tmp_path / "tags.csv").write_text("name\n" + "\n".join(f"tag_{i:05d}" for i in range(n_tags)) + "\n")
+    out = tmp_path / "out"
+    res_full = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint",
+                                str(tmp_path / "dec.pth"), "--image_path", str(imgs), "--tags_csv_path",
+                                str(tmp_path / "tags.csv"), "--output_dir", str(out), "--resolution", str(res),
+                                "--confidence_threshold", "0.5", "--batch_size", "2"])
+    written = json.loads((out / "classification_results.json").read_text())
+    assert written == res_full and len(written) == 3
+    lat = infer_vae.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--image_path", str(imgs),
+                          "--output_dir", str(out), "--resolution", str(res)])
+    assert len(lat) == 3 and all(len(v) == 16 * (res // 8) ** 2 for v in lat.values())
+    # against the CPU oracle on the same preprocessed pixels
+    tf = get_image_transform(res)
+    sd_e.pop("decoder.conv_in.weight")
+    for path, entry in written.items():
+        x = tf(Image.open(path).convert("RGB")).unsqueeze(0)
+        ref_lat = encoder_ref.vae_wrapper_encode(sd_e, x)
+        assert (torch.tensor(lat[path]) - ref_lat.reshape(-1)).abs().max() <= 1e-2
+        conf, idx = decoder_ref.get_confidence(decoder_ref.attention_decoder_forward(sd_d, ref_lat))
+        want = infer_full.summarize(conf[0].tolist(), idx[0].tolist(), [f"tag_{i:05d}" for i in range(n_tags)], 0.5)
+        assert abs(entry["max_confidence"] - want["max_confidence"]) <= 1e-2
+        assert abs(entry["avg_confidence_top5"] - want["avg_confidence_top5"]) <= 1e-2
+        got_tags = {t["tag"] for t in entry["predicted_tags"]}
+        sure = {t["tag"] for t in want["predicted_tags"] if t["confidence"] > 0.51}
+        maybe = {t["tag"] for t in want["predicted_tags"]} | {f"tag_{int(i):05d}" for c, i in zip(conf[0], idx[0]) if c > 0.49}
+        assert sure <= got_tags <= maybe

@@ -233,6 +233,18 @@ int run_gn(vt_context* c, const void* x, int is_f32, int B, int HW, const NormW&
     if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, is_f32, B, HW, n.c, groups, g.partial, &parts, s), "gn_stats");
     g.parts = 0;
     HIPCK(c, vt_launch_gn_finalize(g.partial, parts, B, n.c, groups, 1e-6f, n.g, n.b, g.ss, s), "gn_finalize");
+    if (c->profiling) {
+        vt_context::ProfRec r;
+        r.e0 = c->next_event(); r.e1 = c->next_event();
+        if (!r.e0 || !r.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+        r.flops = (double)B * HW * n.c * (is_f32 ? 6.0 : 4.0);       // algorithmic bytes: one read + one bf16 write
+        r.cfg = VT_PROF_GN_APPLY;
+        HIPCK(c, hipEventRecord(r.e0, s), "hipEventRecord");
+        HIPCK(c, vt_launch_gn_apply(x, is_f32, g.ss, y, B, HW, n.c, silu, s), "gn_apply");
+        HIPCK(c, hipEventRecord(r.e1, s), "hipEventRecord");
+        c->prof.push_back(r);
+        return VT_OK;
+    }
     HIPCK(c, vt_launch_gn_apply(x, is_f32, g.ss, y, B, HW, n.c, silu, s), "gn_apply");
     return VT_OK;
 }
@@ -813,7 +825,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     return c->fail(VT_ERR_INVALID, "vt_set_flag: unknown flag %d", flag);
 }
 
-int vt_profile_num_configs(void) { return VT_NUM_MFMA_CONFIGS; }
+int vt_profile_num_configs(void) { return VT_NUM_PROF_SLOTS; }
 
 // ---- profiling ----------------------------------------------------------------------------------
 int vt_profile_begin(vt_context* c) {
@@ -826,8 +838,8 @@ int vt_profile_end(vt_context* c, int max_cfg, long long* launches, double* tota
                    const char** names) {
     if (!c) return VT_ERR_INVALID;
     c->profiling = false;
-    if (max_cfg < VT_NUM_MFMA_CONFIGS || !launches || !total_ms || !total_flops) return c->fail(VT_ERR_INVALID, "vt_profile_end: need room for %d configurations", VT_NUM_MFMA_CONFIGS);
-    for (int i = 0; i < VT_NUM_MFMA_CONFIGS; ++i) { launches[i] = 0; total_ms[i] = 0; total_flops[i] = 0; if (names) names[i] = vt_conv_gemm_config_name(i); }
+    if (max_cfg < VT_NUM_PROF_SLOTS || !launches || !total_ms || !total_flops) return c->fail(VT_ERR_INVALID, "vt_profile_end: need room for %d slots", VT_NUM_PROF_SLOTS);
+    for (int i = 0; i < VT_NUM_PROF_SLOTS; ++i) { launches[i] = 0; total_ms[i] = 0; total_flops[i] = 0; if (names) names[i] = vt_conv_gemm_config_name(i); }
     for (auto& r : c->prof) {
         HIPCK(c, hipEventSynchronize(r.e1), "hipEventSynchronize");
         float ms = 0.f;

@@ -405,7 +405,10 @@ int vt_conv3x3_halo_tiles(int H, int W, int Cout) {
 
 bool vt_conv3x3_halo_supported(int Cin, int Cout) { return Cin >= 32 && (Cin % 32) == 0 && (Cout % 128) == 0; }
 
-int vt_conv3x3_halo_config(const Conv3x3Args& a) { return (a.Cout % 256) == 0 ? 4 : 3; }   // profile slots 3, 4
+int vt_conv3x3_halo_config(const Conv3x3Args& a) {      // profile slots 3..8 = <tile, XT>
+    const int xt = a.scale_shift ? (a.Xf32 ? 1 : 2) : 0;
+    return 3 + 2 * xt + ((a.Cout % 256) == 0 ? 1 : 0);
+}
 
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
     if (!a.Wp || !a.zeros || (!a.out_f32 && !a.out_bf16)) return hipErrorInvalidValue;

@@ -31,7 +31,9 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s);
 // which tile configuration the dispatcher picks for these args: 0 = 128x32, 1 = 256x128, 2 = 256x256
 int vt_conv_gemm_config(const ConvGemmArgs& a);
 const char* vt_conv_gemm_config_name(int cfg);
-constexpr int VT_NUM_MFMA_CONFIGS = 5;   // 0..2 conv_gemm tiles, 3..4 conv3x3_halo tiles
+constexpr int VT_NUM_MFMA_CONFIGS = 9;   // 0..2 conv_gemm tiles, 3..8 conv3x3_halo <tile, XT>
+constexpr int VT_PROF_GN_APPLY = 9;      // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES
+constexpr int VT_NUM_PROF_SLOTS = 10;
 
 // 3x3 stride-1 pad-1 conv, halo-tile kernel (conv3x3_halo.hip)
 struct Conv3x3Args {
