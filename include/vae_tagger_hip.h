@@ -87,6 +87,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         0 (default) = as a standalone HBM-bound pass (one read + one bf16 write of the tensor).
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
+/* diagnostic (EXP_STAMP) builds only: device buffer that receives per-wave phase cycle counts; NULL otherwise */
+int vt_set_debug_buffer(void* device_ptr);
 
 /* ---- measurement ----------------------------------------------------------------------------
  * Between vt_profile_begin and vt_profile_end every launch of the implicit-GEMM MFMA kernel is

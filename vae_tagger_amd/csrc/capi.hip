@@ -851,6 +851,9 @@ int vt_profile_end(vt_context* c, int max_cfg, long long* launches, double* tota
 }
 
 // ---- single operators ---------------------------------------------------------------------------
+void* g_vt_dbg = nullptr;   // diagnostic builds: set through vt_set_debug_buffer
+extern "C" int vt_set_debug_buffer(void* p) { g_vt_dbg = p; return 0; }
+
 int vt_op_conv2d(vt_context* c, const void* x, const void* w, const float* bias, const float* res, float* o32, void* o16,
                  int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int pad_lo, int pad_hi, void* stream) {
     if (!c) return VT_ERR_INVALID;
@@ -870,6 +873,7 @@ int vt_op_conv2d(vt_context* c, const void* x, const void* w, const float* bias,
         Conv3x3Args h{};
         h.X = (const bf16_t*)x; h.Wp = (const bf16_t*)c->op_scratch; h.bias = bias; h.res = res; h.out_f32 = o32;
         h.out_bf16 = (bf16_t*)o16; h.zeros = c->zeros; h.batch = B; h.H = Hin; h.W = Win; h.Cin = Cin; h.Cout = Cout;
+        h.dbg = (unsigned long long*)g_vt_dbg;
         HIPCK(c, launch_halo(c, h, (hipStream_t)stream), "vt_op_conv2d(halo)");
         return VT_OK;
     }

@@ -50,6 +50,12 @@ __device__ __forceinline__ void wait_vmcnt_tied(int n, V& r0, V& r1) {
     }
 }
 
+#ifdef EXP_STAMP
+#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(v) do { } while (0)
+#endif
+
 // Identity the optimiser cannot see through: stops loop-invariant address arithmetic built on `v` from being
 // hoisted into (and spilled from) long-lived registers -- it is recomputed where it is used instead.
 __device__ __forceinline__ int opaque(int v) {
@@ -80,9 +86,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     constexpr int BC = WC * 64;                  // couts per workgroup (each wave: 64)
     constexpr int TP = 8, TC = 4;
     constexpr int HROWS = (ROWS + 2) * HWID;     // halo pixels
-    constexpr int NXW = (HROWS + 127) / 128;     // X staging wave-instructions per wave (16 rows each, 8 waves)
-    constexpr int XBUF = NXW * 128 * HB;         // bytes per X halo buffer
-    constexpr int WPW = BC / 128;                // W DMA wave-instructions per wave per K-step
+    constexpr int NLD = 8;                       // every wave issues its share of the DMA pieces
+    constexpr int NXW = ((HROWS + 15) / 16 + NLD - 1) / NLD;   // X staging wave-instructions per issuing wave (16 rows each)
+    constexpr int XBUF = NXW * NLD * 16 * HB;    // bytes per X halo buffer
+    constexpr int WPW = BC / (16 * NLD);         // W DMA wave-instructions per issuing wave per K-step
     constexpr int WBUF = BC * HB;                // bytes per W stage
     constexpr int LX = XT == 1 ? 2 : 1;          // register loads per staged row (8 channels)
     constexpr int DLY = XT == 1 ? 2 : 3;         // K-steps between a row's load and its normalise+write
@@ -121,35 +128,48 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     // chunk (l & 3); logical chunk = physical ^ swz(row), swz(row) = ((row >> 2) & 1) << 1 = ((l >> 4) & 1) << 1.
     const int drow = lane >> 2;
     const int dchunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
-    int xsrc[NXW];          // element offset of (halo pixel, logical chunk) in the image, or -1 if outside
+    // XT != 0 keeps one source offset per staged row (also needed when the row is written); XT == 0 derives the
+    // DMA addresses on the fly from the lane's first halo row (fewer live registers in the MFMA loop).
+    constexpr int NXS = XT == 0 ? 1 : NXW;
+    int xsrc[NXS];          // element offset of (halo pixel, logical chunk) in the image, or -1 if outside
+    if constexpr (XT != 0) {
 #pragma unroll
-    for (int j = 0; j < NXW; ++j) {
-        const int hr = (j * 8 + wave) * 16 + drow;
-        const int hy = hr / HWID, hx = hr - hy * HWID;
-        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-        const bool v = hr < HROWS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        xsrc[j] = v ? (iy * a.W + ix) * a.Cin + dchunk * 8 : -1;
+        for (int j = 0; j < NXW; ++j) {
+            const int hr = (j * NLD + wave) * 16 + drow;
+            const int hy = hr / HWID, hx = hr - hy * HWID;
+            const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+            const bool v = hr < HROWS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            xsrc[j] = v ? (iy * a.W + ix) * a.Cin + dchunk * 8 : -1;
+        }
+    } else {
+        xsrc[0] = 0;
     }
-    // W: Wp[chunk][tap][Cout][32]; this lane's row inside the K-step tile
-    int wsrc[WPW];
-#pragma unroll
-    for (int j = 0; j < WPW; ++j) wsrc[j] = (c0 + (j * 8 + wave) * 16 + drow) * 32 + dchunk * 8;
+    const int hr0 = wave * 16 + drow;            // this lane's halo row in piece j = 0 (XT == 0 path)
+    const int hy0 = hr0 / HWID, hx0 = hr0 - (hr0 / HWID) * HWID;
+    // W: Wp[chunk][tap][Cout][32]; this lane's row inside the K-step tile, piece j = 0
+    const int wsrc0 = (c0 + wave * 16 + drow) * 32 + dchunk * 8;
     const int wstep = a.Cout * 32;               // elements between consecutive K-steps
 
     auto issue_x_dma = [&](int chunk) {          // XT == 0
         char* dst = xbase + (chunk & 1) * XBUF;
-#pragma unroll
-        for (int j = 0; j < NXW; ++j) {
-            const void* src = xsrc[j] >= 0 ? (const void*)(Xb + (xsrc[j] + chunk * 32)) : a.zeros;
-            __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(dst + (j * 8 + wave) * 1024), 16, 0, 0);
+        int hy = opaque(hy0), hx = hx0, hr = hr0;
+#pragma nounroll
+        for (int j = 0; j < NXW; ++j) {                              // rolled: few live temporaries beside the accumulators
+            const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+            const bool v = hr < HROWS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const void* src = v ? (const void*)(Xb + ((iy * a.W + ix) * a.Cin + dchunk * 8 + chunk * 32)) : a.zeros;
+            __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(dst + (j * NLD + wave) * 1024), 16, 0, 0);
+            hr += NLD * 16;                                         // next piece: NLD*16 halo rows further
+            hx += (NLD * 16) % HWID; hy += (NLD * 16) / HWID;
+            if (hx >= HWID) { hx -= HWID; ++hy; }
         }
     };
     auto issue_w = [&](int t) {
         char* dst = wbase + (t % NW) * WBUF;
-        const bf16_t* wt = a.Wp + (long long)t * wstep;
+        const bf16_t* wt = a.Wp + (long long)t * wstep + opaque(wsrc0);
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
-            __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(wt + wsrc[j]), VT_LDS_PTR(dst + (j * 8 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(wt + j * NLD * 16 * 32), VT_LDS_PTR(dst + (j * NLD + wave) * 1024), 16, 0, 0);
     };
     // register-staged row: 8 channels of one halo pixel (XT 1: 2 x 16 B of fp32, XT 2: 16 B of bf16)
     auto load_row = [&](int j, int chunk, f32x4& r0, f32x4& r1) {
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     // y = silu(x * scale + shift) -> bf16, written where the DMA would have put the raw row
     auto write_row = [&](int j, int chunk, const f32x4& r0, const f32x4& r1) {
         const float* sp = ssl + (chunk * 32 + opaque(dchunk) * 8) * 2;
-        char* dst = xbase + (chunk & 1) * XBUF + (j * 8 + wave) * 1024 + opaque(lane) * 16;
+        char* dst = xbase + (chunk & 1) * XBUF + (j * NLD + wave) * 1024 + opaque(lane) * 16;
         const bool pad = xsrc[j] < 0;                              // conv zero padding applies AFTER norm + SiLU
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -229,15 +249,44 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
             write_row(j, 0, r0, r1);
         }
     }
+    // SPF (software-pipelined fragments, XT == 0): the MFMA operands of step t+1 are read from LDS DURING step t
+    // (a second W-fragment register set; each X fragment is refilled as soon as its last MFMA has issued), so
+    // after a barrier the matrix pipe starts at once instead of waiting ~250 cycles for 12 ds_read_b128.  That
+    // needs W(t+1) landed at the barrier of step t: the ring is filled one step further ahead (W(t+NW) is issued
+    // at step t into the stage whose fragments were read during step t-1).
+    constexpr bool SPF = XT == 0;
+    constexpr int LEAD = SPF ? NW : NW - 1;      // W(t + LEAD) is issued at step t
 #pragma unroll
-    for (int t = 0; t < NW - 1; ++t)
+    for (int t = 0; t < LEAD; ++t)
         if (t < nk) issue_w(t);
+
+    bf16x8 wfc[TC], xfr[TP];                     // SPF: fragments of the step about to run
+#ifdef EXP_STAMP
+    unsigned long long dsum[5] = {0, 0, 0, 0, 0};
+    unsigned long long Tk0; STAMP(Tk0);
+#endif
+    if constexpr (SPF) {
+        int ahead0 = nk - 1;
+        if (ahead0 > NW - 1) ahead0 = NW - 1;
+        wait_vmcnt(ahead0 * WPW);                // W(0) and X(0) landed (this wave's pieces) ...
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // ... and everybody else's
+        asm volatile("" ::: "memory");
+        const char* ws0 = wbase + opaque(wfoff);
+#pragma unroll
+        for (int i = 0; i < TC; ++i) wfc[i] = *(const bf16x8*)(ws0 + i * 16 * HB);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int rel = j * HWID;            // tap 0: dy = dx = 0
+            xfr[j] = *(const bf16x8*)(xbase + xsel[rel & 7] + rel * HB);
+        }
+    }
 
     // One chunk = 9 K-steps (taps).  LAST = the final chunk: no next halo, weight ring drains, so the
     // wait count is computed at run time; every other chunk's counts fold to immediates after unrolling.
-    // VM-op issue order per wave and step: [wait][barrier] W(t+NW-1) [then, XT != 0 and tap < NXW: row `tap` of
-    // the next chunk's halo].  All VM ops retire in order, so "at most N outstanding" with N = number of ops
-    // ISSUED after op X  <=>  X has landed.
+    // VM-op issue order per wave and step: [wait][barrier] W(t+LEAD) [then the next chunk's halo: XT == 0 at tap 0
+    // by DMA; XT != 0 row `tap` at the end of the step].  All VM ops retire in order, so "at most N outstanding"
+    // with N = number of ops ISSUED after op X  <=>  X has landed.
     auto do_chunk = [&](int chunk, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const char* xs = xbase + (chunk & 1) * XBUF;
@@ -246,23 +295,71 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int t = tbase + tap;
+            [[maybe_unused]] unsigned long long T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0;
+            STAMP(T0);
+            // the operand needed at this barrier: W(t) -- or W(t+1) with SPF, whose fragments are read during
+            // this step.  Ops issued after it: the next NW-2 weight tiles (+ the next halo inside its window).
             if constexpr (!LAST) {
-                int n = (NW - 2) * WPW;           // W(t+1 .. t+NW-2)
+                int n = (NW - 2) * WPW;
                 if (XT == 0) { if (tap >= 1 && tap <= NW - 1) n += NXW; }                 // next halo, DMA'd at tap 0
                 else { for (int r = tap - (NW - 1); r <= tap - 1; ++r) if (r >= 0 && r < NXW) n += LX; }
                 wait_vmcnt(n);
             } else {
-                int ahead = nk - 1 - t;
+                int ahead = nk - 1 - (SPF ? t + 1 : t);
                 if (ahead > NW - 2) ahead = NW - 2;
+                if (ahead < 0) ahead = 0;
                 wait_vmcnt(ahead * WPW);
             }
             if (XT != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's staged rows are written
+            STAMP(T1);
             asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();        // all waves' pieces of W(t) (and X(chunk)) are in LDS;
-            asm volatile("" ::: "memory");       // everyone is done reading stage (t-1) % NW
-            if (!LAST || t + NW - 1 < nk) issue_w(t + NW - 1);
-            if constexpr (!LAST && XT == 0) { if (tap == 0) issue_x_dma(chunk + 1); }
+            __builtin_amdgcn_s_barrier();        // all waves' pieces of the tile (and X(chunk)) are in LDS;
+            asm volatile("" ::: "memory");       // everyone is done reading the stage that is refilled next
+            STAMP(T2);
+            if constexpr (!SPF) {
+                if (!LAST || t + LEAD < nk) issue_w(t + LEAD);
+            }
+            STAMP(T3);
 
+            if constexpr (SPF) {
+                // MFMAs of step t on registers filled during step t-1; meanwhile fetch step t+1's fragments
+                const bool has_next = !LAST || t + 1 < nk;
+                const int tap_n = (tap + 1) % 9;
+                const int dy_n = tap_n / 3, dx_n = tap_n % 3;
+                const char* xs_n = (tap == 8) ? xbase + ((chunk + 1) & 1) * XBUF : xs;
+                const char* ws_n = wbase + ((t + 1) % NW) * WBUF + opaque(wfoff);
+                // An LDS-DMA piece costs its wave ~100 issue cycles.  Issued right after the barrier by all 8 waves
+                // at once, that kept the matrix pipe idle (~190 cycles per K-step, in-kernel stamps); instead each
+                // wave slips its pieces into the MIDDLE of its MFMA sequence.  The older wave of a SIMD pair wins MFMA
+                // arbitration and reaches that point ~200 cycles before its partner, so one wave's DMA issue runs
+                // beside the other's MFMAs.
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+#pragma unroll
+                    for (int i = 0; i < TC; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[i], xfr[j], acc[i][j], 0, 0, 0);
+                    if (has_next) {
+                        const int rel = (j + dy_n) * HWID + dx_n;
+                        xfr[j] = *(const bf16x8*)(xs_n + xsel[rel & 7] + rel * HB);     // its last reader has issued
+                    }
+                    if (j == 3) {
+                        if (!LAST || t + LEAD < nk) issue_w(t + LEAD);
+                        if constexpr (!LAST) { if (tap == 0) issue_x_dma(chunk + 1); }
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (has_next) {
+                    // W fragments are live until the last MFMA: refill them now; the reads fly during the barrier wait
+#pragma unroll
+                    for (int i = 0; i < TC; ++i) wfc[i] = *(const bf16x8*)(ws_n + i * 16 * HB);
+                }
+#ifdef EXP_STAMP
+                STAMP(T4);
+                dsum[0] += T1 - T0; dsum[1] += T2 - T1; dsum[2] += T3 - T2; dsum[3] += T4 - T3; dsum[4] += 1;
+#endif
+                continue;
+            }
             const char* ws = wbase + (t % NW) * WBUF + opaque(wfoff);     // stage bases beyond 64 KB cannot be ds_read immediates
             const int dy = tap / 3, dx = tap % 3;
             bf16x8 wf[TC];
@@ -322,6 +419,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     for (int chunk = 0; chunk + 1 < nchunk; ++chunk) do_chunk(chunk, std::false_type{});
     do_chunk(nchunk - 1, std::true_type{});
 
+#ifdef EXP_STAMP
+    unsigned long long Tk1; STAMP(Tk1);
+#endif
     // ---- epilogue: lane holds couts cg..cg+3 of pixel (y, x) for every (i, j)
     const int HWp = a.H * a.W;
     const long long ob = (long long)b * HWp * a.Cout;
@@ -349,6 +449,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
             acc[i][j] = v;
         }
     }
+#ifdef EXP_STAMP
+    if (a.dbg && lane == 0) {
+        unsigned long long Tk2; STAMP(Tk2);
+        unsigned long long* d = a.dbg + ((long long)blockIdx.x * 8 + wave) * 8;
+        d[0] = dsum[0]; d[1] = dsum[1]; d[2] = dsum[2]; d[3] = dsum[3]; d[4] = dsum[4]; d[5] = Tk1 - Tk0; d[6] = Tk2 - Tk1;
+    }
+#endif
     if (a.gn_partial) {
         // GroupNorm statistics of this tile's outputs for the NEXT layer's norm (replaces a full read pass)
         __syncthreads();                                   // every wave is done with the staging LDS
@@ -362,8 +469,9 @@ template <int WP, int WC, int XT>
 hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
     constexpr int ROWS = WP * 8, BC = WC * 64;
     constexpr int HROWS = (ROWS + 2) * HWID;
-    constexpr int NXW = (HROWS + 127) / 128;
-    const int smem = 2 * NXW * 128 * HB + NW * BC * HB + (XT ? a.Cin * 8 : 0);
+    constexpr int NLD = 8;
+    constexpr int NXW = ((HROWS + 15) / 16 + NLD - 1) / NLD;
+    const int smem = 2 * NXW * NLD * 16 * HB + NW * BC * HB + (XT ? a.Cin * 8 : 0);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
     auto kern = conv3x3_halo_kernel<WP, WC, XT>;

@@ -49,6 +49,7 @@ struct Conv3x3Args {
     float* gn_partial;      // optional [batch][tiles][Cout/gn_cpg][3] (n, mean, M2) of the output values
     int gn_cpg;             // channels per GroupNorm group of the OUTPUT (4, 8 or 16)
     int batch, H, W, Cin, Cout;
+    unsigned long long* dbg; // diagnostic builds only (EXP_STAMP): per-wave phase cycle sums
 };
 int vt_conv3x3_halo_tiles(int H, int W, int Cout);
 int vt_conv_gemm_ptiles(int HWo, int Cout);
