@@ -39,6 +39,9 @@ def parse():
     p.add_argument("--width", type=int, default=1024)
     p.add_argument("--tags", type=int, default=10000)
     p.add_argument("--encode-only", action="store_true", help="BASELINE configs[1]: encoder only")
+    p.add_argument("--bucketed", action="store_true",
+                   help="BASELINE configs[3]: same-shape batches drawn from the reference's 512..1024 step-64 aspect buckets")
+    p.add_argument("--bucket-batch", type=int, default=8, help="images per same-shape batch in --bucketed mode")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--generic-conv", action="store_true", help="A/B: disable the halo-tile 3x3 kernel")
     p.add_argument("--cpu-sample-res", type=int, default=1024)
@@ -104,11 +107,47 @@ def main():
         pipe.ctx.call("vt_set_flag", 0, 0)
 
     B = a.batch
-    # synthetic inputs, resident in HBM before the timed region; distinct per rank (global batch = world*B)
-    x = synth.synth_images(B, a.height, a.width, seed=1000 + rank).to(dev)
     counts = [B] * world
+    images_per_step = world * B
+    flops_step = None
+    if a.bucketed:
+        # reference AspectRatioBucketing(512, 1024, 64) (modules.py:180-222, train_full.sh:13-16): the buckets an
+        # image can actually be assigned to, a seeded draw of 2*world same-shape batches per step, whole batches
+        # placed on ranks by the FLOP cost model (conv ~ pixels, attention ~ pixels^2)
+        import random
+        from vae_tagger_amd.modules import AspectRatioBucketing
+        bk = AspectRatioBucketing(512, 1024, 64)
+        reach = sorted({bk.bucket_for_ratio(w / h) for w in range(256, 2049, 8) for h in range(256, 2049, 8)})
+        rng = random.Random(0)
+        plan = []                                       # per step: [(w, h, n)] and the assignment
+        for _ in range(a.warmup + a.steps):
+            batches = [(*rng.choice(reach), a.bucket_batch) for _ in range(2 * world)]
+            assign, _ = sharding.assign_batches(batches, world)
+            plan.append((batches, assign))
+        cache = {}
+
+        def bucket_input(w, h):
+            if (w, h) not in cache:
+                cache[(w, h)] = synth.synth_images(a.bucket_batch, h, w, seed=w * 4096 + h + rank).to(dev)
+            return cache[(w, h)]
+        for batches, assign in plan:                    # inputs resident in HBM before timing
+            for i in assign[rank]:
+                bucket_input(batches[i][0], batches[i][1])
+        images_per_step = 2 * world * a.bucket_batch
+        flops_step = [sum(pipe.flops_per_image(h, w) * n for (w, h, n) in b) for b, _ in plan[a.warmup:]]
+        it = iter(plan)
+    else:
+        # synthetic inputs, resident in HBM before the timed region; distinct per rank (global batch = world*B)
+        x = synth.synth_images(B, a.height, a.width, seed=1000 + rank).to(dev)
 
     def step():
+        if a.bucketed:
+            batches, assign = next(it)
+            outs = [pipe.logits(bucket_input(batches[i][0], batches[i][1])) for i in assign[rank]]
+            local = torch.cat(outs, dim=0) if outs else torch.empty(0, a.tags, device=dev)
+            if world == 1:
+                return local
+            return sharding.all_gather_logits(local, [sum(batches[i][2] for i in assign[r]) for r in range(world)])
         if a.encode_only:
             return vae_model.encode(x)
         logits = pipe.logits(x)
@@ -144,22 +183,28 @@ def main():
 
     if rank == 0:
         flops_img = pipe.flops_per_image(a.height, a.width)
-        ips = world * B * a.steps / elapsed
+        ips = images_per_step * a.steps / elapsed
+        if flops_step is not None:
+            flops_img = sum(flops_step) / (images_per_step * a.steps)      # mean over the drawn buckets
         nm = n - 1                                   # MFMA kernel slots; the last slot is the HBM-bound GroupNorm pass
         dom = max(range(nm), key=lambda i: tot_ms[i])
         achieved = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
         gemm_ms = sum(tot_ms[i] for i in range(nm))
         gn_gbs = tot_fl[nm] / (tot_ms[nm] * 1e-3) / 1e9 if tot_ms[nm] > 0 else 0.0
         res = {
-            "metric": "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16",
+            "metric": ("images/sec encode+tag, bucketed 512..1024 bf16" if a.bucketed else
+                       "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("configs[2]: " if not a.encode_only else "configs[1]: ")
-                       + f"batch {B}/GPU {a.width}x{a.height} FLUX-VAE encode"
-                       + ("" if a.encode_only else f" + 8-head attention decoder, {a.tags} tags")
+            "config": {"workload": (f"configs[3]: bucketed 512->1024 step 64 (67 reachable buckets), {2 * world} same-shape batches of "
+                                    f"{a.bucket_batch} per step, FLUX-VAE encode + 8-head attention decoder, {a.tags} tags"
+                                    if a.bucketed else
+                                    ("configs[2]: " if not a.encode_only else "configs[1]: ")
+                                    + f"batch {B}/GPU {a.width}x{a.height} FLUX-VAE encode"
+                                    + ("" if a.encode_only else f" + 8-head attention decoder, {a.tags} tags"))
                        + ", random-init weights (seeded), fp32 NCHW input resident in HBM",
-                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "global_batch": images_per_step, "parallelism": f"dp{world}",
                        "tflop_per_image": round(flops_img / 1e12, 4),
                        "end_to_end_tflops_per_gpu": round(ips / world * flops_img / 1e12, 2),
                        "end_to_end_frac_of_mfma_peak": round(ips / world * flops_img / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)},

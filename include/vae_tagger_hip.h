@@ -75,6 +75,10 @@ size_t vt_encode_tag_workspace_bytes(const vt_context* ctx, int B, int H, int W)
 int vt_encode_tag(vt_context* ctx, const float* x_nchw, int B, int H, int W, float* latent_out /* may be NULL */,
                   float* logits_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* vt_preprocess_u8 <- transforms.ToTensor() + Normalize([0.5]*3, [0.5]*3), modules.py:136-140, on the device:
+ * uint8 HWC RGB [B,H,W,3] -> fp32 NCHW [B,3,H,W] in [-1,1] (the resize stays with PIL on the host). */
+int vt_preprocess_u8(vt_context* ctx, const uint8_t* in_hwc, int B, int H, int W, float* out_nchw, void* stream);
+
 /* algorithmic FLOPs of one encoder forward at HxW -- for roofline reporting */
 double vt_encoder_flops(const vt_context* ctx, int H, int W);
 

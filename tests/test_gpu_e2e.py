@@ -171,3 +171,13 @@ def test_full_size_properties(vae):
     # oracle through statistics the goldens recorded at 512^2 (same weights, same input distribution)
     g = golden("encoder_enc_512x512")["latent"]
     assert abs(a.mean().item() - g.mean().item()) < 0.02 and abs(a.std().item() - g.std().item()) < 0.02
+
+
+def test_device_preprocess_is_bit_exact_with_totensor_normalize(vae):
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+    pipe = EncodeTagPipeline(vae, _decoder(11))
+    u8 = torch.randint(0, 256, (2, 37, 53, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    u8[0, 0, 0] = torch.tensor([0, 127, 255], dtype=torch.uint8)
+    ref = (u8.permute(0, 3, 1, 2).to(torch.float32).div(255.0) - 0.5) / 0.5       # ToTensor + Normalize(0.5, 0.5)
+    got = pipe.normalize_u8(u8.cuda()).cpu()
+    assert torch.equal(got, ref)

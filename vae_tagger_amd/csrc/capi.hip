@@ -827,6 +827,12 @@ int vt_set_flag(vt_context* c, int flag, int value) {
 
 int vt_profile_num_configs(void) { return VT_NUM_PROF_SLOTS; }
 
+int vt_preprocess_u8(vt_context* c, const uint8_t* in_hwc, int B, int H, int W, float* out_nchw, void* stream) {
+    if (!c) return VT_ERR_INVALID;
+    HIPCK(c, vt_launch_preprocess_u8(in_hwc, out_nchw, B, H, W, (hipStream_t)stream), "vt_preprocess_u8");
+    return VT_OK;
+}
+
 // ---- profiling ----------------------------------------------------------------------------------
 int vt_profile_begin(vt_context* c) {
     if (!c) return VT_ERR_INVALID;

@@ -195,7 +195,30 @@ __global__ __launch_bounds__(256) void softmax_rows_cached_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ToTensor + Normalize(0.5, 0.5) on the device: uint8 HWC RGB -> fp32 NCHW in [-1, 1], the tensor the
+// reference builds on the CPU (modules.py:136-140).  Same fp32 operations as torch: x/255, then (x-0.5)/0.5.
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ in, float* __restrict__ out,
+                                                            long long HW) {
+    const int b = blockIdx.y;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const unsigned char* src = in + ((long long)b * HW + p) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = __fdiv_rn((float)src[c], 255.0f);
+        out[((long long)b * 3 + c) * HW + p] = (v - 0.5f) / 0.5f;
+    }
+}
+
 }  // namespace
+
+hipError_t vt_launch_preprocess_u8(const unsigned char* in_hwc, float* out_nchw, int B, int H, int W, hipStream_t s) {
+    if (!in_hwc || !out_nchw || B <= 0 || H <= 0 || W <= 0) return hipErrorInvalidValue;
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, s, in_hwc, out_nchw, HW);
+    return hipGetLastError();
+}
 
 hipError_t vt_launch_conv_in(const float* x, const float* wp, const float* bias, float* o32, bf16_t* o16,
                              float* gn_partial, int gn_cpg, int* gn_parts, int B, int H, int W, int Cout, hipStream_t s) {

@@ -77,6 +77,8 @@ int vt_gn_max_chunks(int HW, int C);
 hipError_t vt_launch_gn_apply(const void* x, int x_is_f32, const float* scale_shift, bf16_t* y, int B, int HW,
                               int C, int silu, hipStream_t s);
 
+hipError_t vt_launch_preprocess_u8(const unsigned char* in_hwc, float* out_nchw, int B, int H, int W, hipStream_t s);
+
 // row softmax: scores fp32 [rows][lds] -> probs bf16 [rows][ldp]; columns [n, ldp) are written as zero.
 hipError_t vt_launch_softmax_rows(const float* scores, bf16_t* probs, int rows, int n, int lds, int ldp,
                                   hipStream_t s);

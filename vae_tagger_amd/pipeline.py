@@ -62,5 +62,17 @@ class EncodeTagPipeline:
         self.ctx.call("vt_get_confidence", vp(logits), B, N, vp(conf), vp(idx), stream_ptr(logits.device))
         return conf, idx
 
+    @torch.no_grad()
+    def normalize_u8(self, u8_hwc):
+        """ToTensor + Normalize(0.5, 0.5) on the device: uint8 [B,H,W,3] -> fp32 NCHW in [-1,1] (modules.py:136-140).
+        Uploading uint8 moves 4x fewer bytes over PCIe than the fp32 tensor the reference builds on the CPU."""
+        u8 = u8_hwc.to(self.device).contiguous()
+        if u8.dtype != torch.uint8 or u8.dim() != 4 or u8.shape[-1] != 3:
+            raise ValueError(f"expected uint8 [B,H,W,3], got {u8.dtype} {tuple(u8.shape)}")
+        B, H, W, _ = u8.shape
+        out = torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device)
+        self.ctx.call("vt_preprocess_u8", vp(u8), B, H, W, vp(out), stream_ptr(self.device))
+        return out
+
     def tag(self, x):
         return self.confidence(self.logits(x))
