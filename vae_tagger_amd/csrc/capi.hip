@@ -822,6 +822,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 0) { c->use_halo_conv = value != 0; return VT_OK; }
     if (flag == 1) { c->fuse_gn_stats = value != 0; return VT_OK; }
     if (flag == 2) { c->fuse_gn_apply = value != 0; return VT_OK; }
+    if (flag == 3) { vt_conv3x3_halo_set_waves(value); return VT_OK; }      // process-wide: halo kernel geometry
     return c->fail(VT_ERR_INVALID, "vt_set_flag: unknown flag %d", flag);
 }
 

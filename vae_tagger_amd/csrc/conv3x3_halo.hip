@@ -79,17 +79,22 @@ __device__ __forceinline__ void wait_vmcnt_tied1(int n, V& r0) {
 //      hand-counted inline-asm global loads, GroupNorm'ed with the per-(image, channel) (scale, shift) the
 //      previous layer's epilogue statistics produced, SiLU'ed, rounded to bf16 and written to LDS -- the
 //      standalone GroupNorm+SiLU pass (one read + one write of the whole tensor) disappears.
-template <int WP, int WC, int XT>
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) {
-    static_assert(WP * WC == 8, "8 waves");
-    constexpr int ROWS = WP * 8;                 // tile rows (each wave: 8 rows x 16 px)
+// TPW = tile rows per wave: 8 with 8 waves (2 per SIMD, <= 256 VGPRs), 4 with 16 waves (4 per SIMD, <= 128 VGPRs:
+// twice the instruction streams per SIMD to fill each other's non-MFMA gaps).
+template <int WP, int WC, int XT, int TPW>
+__global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x3Args a) {
+    constexpr int NWV = WP * WC;                 // waves per workgroup
+    constexpr int NT = 64 * NWV;
+    static_assert((NWV == 8 && TPW == 8) || (NWV == 16 && TPW == 4 && XT == 0), "8 waves x 8 rows or 16 waves x 4 rows");
+    constexpr int ROWS = WP * TPW;               // tile rows (each wave: TPW rows x 16 px)
     constexpr int BC = WC * 64;                  // couts per workgroup (each wave: 64)
-    constexpr int TP = 8, TC = 4;
+    constexpr int TP = TPW, TC = 4;
     constexpr int HROWS = (ROWS + 2) * HWID;     // halo pixels
-    constexpr int NLD = 8;                       // every wave issues its share of the DMA pieces
+    constexpr int NLD = NWV;                     // every wave issues its share of the DMA pieces
     constexpr int NXW = ((HROWS + 15) / 16 + NLD - 1) / NLD;   // X staging wave-instructions per issuing wave (16 rows each)
     constexpr int XBUF = NXW * NLD * 16 * HB;    // bytes per X halo buffer
-    constexpr int WPW = BC / (16 * NLD);         // W DMA wave-instructions per issuing wave per K-step
+    constexpr int WPCS = BC / 16;                // W DMA pieces per K-step
+    constexpr int WPW = (WPCS + NLD - 1) / NLD;  // ... per issuing wave (waves >= WPCS issue none when WPCS < NLD)
     constexpr int WBUF = BC * HB;                // bytes per W stage
     constexpr int LX = XT == 1 ? 2 : 1;          // register loads per staged row (8 channels)
     constexpr int DLY = XT == 1 ? 2 : 3;         // K-steps between a row's load and its normalise+write
@@ -105,6 +110,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wp = wave / WC, wc = wave % WC;
     const bool early = wave < 4;                 // staging phase of this wave (see the K-loop)
+    // W DMA pieces THIS wave issues per K-step (the vmcnt arithmetic below is per wave)
+    const int wpw = (WPCS % NLD == 0) ? WPW : (wave < WPCS % NLD ? WPW : WPW - 1);
 
     // ---- tile coordinates
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + ROWS - 1) / ROWS;
@@ -169,7 +176,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
         const bf16_t* wt = a.Wp + (long long)t * wstep + opaque(wsrc0);
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
-            __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(wt + j * NLD * 16 * 32), VT_LDS_PTR(dst + (j * NLD + wave) * 1024), 16, 0, 0);
+            if (WPCS % NLD == 0 || j * NLD + wave < WPCS)
+                __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(wt + j * NLD * 16 * 32), VT_LDS_PTR(dst + (j * NLD + wave) * 1024), 16, 0, 0);
     };
     // register-staged row: 8 channels of one halo pixel (XT 1: 2 x 16 B of fp32, XT 2: 16 B of bf16)
     auto load_row = [&](int j, int chunk, f32x4& r0, f32x4& r1) {
@@ -223,10 +231,23 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     // The swizzle bit of row hr is bit 2 of (R + fr), a function of (R & 7, fr) only, and R & 7 =
     // ((j+dy)*18 + dx) & 7 is a compile-time constant (wp*144 is a multiple of 8).  So 8 per-lane base
     // addresses (one per value of R & 7) plus ds_read immediate offsets cover all 72 (tap, j) reads.
-    int xsel[8];
+    // 8-wave variants keep the 8 addresses in registers; the 16-wave variants (128-VGPR budget) keep one base
+    // address plus an 8-bit per-lane mask and rebuild the address with 2 VALU ops per read.
+    constexpr bool XSEL_REGS = true;   // (rebuilding the address per read made the 16-wave variants spill more, not less)
+    int xsel[XSEL_REGS ? 8 : 1];
+    const int xa0 = (wp * TPW * HWID + fr) * HB + (fq << 4);
+    int xmask8 = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        xsel[k] = (wp * 8 * HWID + fr) * HB + ((fq ^ ((((k + fr) >> 2) & 1) << 1)) << 4);
+    for (int k = 0; k < 8; ++k) {
+        const int bit = ((k + fr) >> 2) & 1;
+        if constexpr (XSEL_REGS) xsel[k] = xa0 ^ (bit << 5);
+        xmask8 |= bit << k;
+    }
+    if constexpr (!XSEL_REGS) xsel[0] = 0;
+    auto xaddr = [&](int k) -> int {                       // k is a compile-time constant after unrolling
+        if constexpr (XSEL_REGS) return xsel[k];
+        else return opaque(xa0) ^ (((xmask8 >> k) & 1) << 5);
+    };
     f32x4 acc[TC][TP];
 #pragma unroll
     for (int i = 0; i < TC; ++i)
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
         issue_x_dma(0);
     } else {
         const float* ssg = a.scale_shift + (long long)b * a.Cin * 2;
-        for (int i = threadIdx.x; i < a.Cin * 2; i += 512) ssl[i] = ssg[i];
+        for (int i = threadIdx.x; i < a.Cin * 2; i += NT) ssl[i] = ssg[i];
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NXW; ++j) {
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     if constexpr (SPF) {
         int ahead0 = nk - 1;
         if (ahead0 > NW - 1) ahead0 = NW - 1;
-        wait_vmcnt(ahead0 * WPW);                // W(0) and X(0) landed (this wave's pieces) ...
+        wait_vmcnt(ahead0 * wpw);                // W(0) and X(0) landed (this wave's pieces) ...
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();            // ... and everybody else's
         asm volatile("" ::: "memory");
@@ -278,7 +299,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int rel = j * HWID;            // tap 0: dy = dx = 0
-            xfr[j] = *(const bf16x8*)(xbase + xsel[rel & 7] + rel * HB);
+            xfr[j] = *(const bf16x8*)(xbase + xaddr(rel & 7) + rel * HB);
         }
     }
 
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
             // the operand needed at this barrier: W(t) -- or W(t+1) with SPF, whose fragments are read during
             // this step.  Ops issued after it: the next NW-2 weight tiles (+ the next halo inside its window).
             if constexpr (!LAST) {
-                int n = (NW - 2) * WPW;
+                int n = (NW - 2) * wpw;
                 if (XT == 0) { if (tap >= 1 && tap <= NW - 1) n += NXW; }                 // next halo, DMA'd at tap 0
                 else { for (int r = tap - (NW - 1); r <= tap - 1; ++r) if (r >= 0 && r < NXW) n += LX; }
                 wait_vmcnt(n);
@@ -308,7 +329,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
                 int ahead = nk - 1 - (SPF ? t + 1 : t);
                 if (ahead > NW - 2) ahead = NW - 2;
                 if (ahead < 0) ahead = 0;
-                wait_vmcnt(ahead * WPW);
+                wait_vmcnt(ahead * wpw);
             }
             if (XT != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's staged rows are written
             STAMP(T1);
@@ -333,7 +354,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
                 // wave slips its pieces into the MIDDLE of its MFMA sequence.  The older wave of a SIMD pair wins MFMA
                 // arbitration and reaches that point ~200 cycles before its partner, so one wave's DMA issue runs
                 // beside the other's MFMAs.
+#if defined(EXP_PRIO_NONE)
+#elif defined(EXP_PRIO_YOUNG)
+                if (early) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
+#else
                 __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
 #pragma unroll
@@ -341,9 +367,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[i], xfr[j], acc[i][j], 0, 0, 0);
                     if (has_next) {
                         const int rel = (j + dy_n) * HWID + dx_n;
-                        xfr[j] = *(const bf16x8*)(xs_n + xsel[rel & 7] + rel * HB);     // its last reader has issued
+                        xfr[j] = *(const bf16x8*)(xs_n + xaddr(rel & 7) + rel * HB);     // its last reader has issued
                     }
-                    if (j == 3) {
+                    if (j == TP / 2 - 1) {
                         if (!LAST || t + LEAD < nk) issue_w(t + LEAD);
                         if constexpr (!LAST) { if (tap == 0) issue_x_dma(chunk + 1); }
                     }
@@ -373,7 +399,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
             constexpr bool STAGE = !LAST && XT != 0;
             const int r = tap - DLY;
             auto stage_row = [&]() {
-                int n = DLY * WPW;                // W issued in steps r+1 .. tap (this step's W is already out)
+                int n = DLY * wpw;                // W issued in steps r+1 .. tap (this step's W is already out)
                 for (int q = r + 1; q < tap; ++q) if (q < NXW) n += LX;          // rows r+1 .. tap-1
 #ifndef EXP_NOWAIT
                 if constexpr (XT == 1) wait_vmcnt_tied(n, rq[r % DLY][0], rq[r % DLY][1]);
@@ -394,7 +420,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int rel = (jh + j + dy) * HWID + dx;            // compile-time after unrolling
-                    xf[j] = *(const bf16x8*)(xs + xsel[rel & 7] + rel * HB);
+                    xf[j] = *(const bf16x8*)(xs + xaddr(rel & 7) + rel * HB);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -429,7 +455,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     unsigned valid = 0;
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
-        const int y = ty0 + wp * 8 + j;
+        const int y = ty0 + wp * TPW + j;
         if (y >= a.H || x >= a.W) continue;
         valid |= 1u << j;
         const long long p = (long long)y * a.W + x;
@@ -465,16 +491,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3x3Args a) 
     }
 }
 
-template <int WP, int WC, int XT>
+template <int WP, int WC, int XT, int TPW>
 hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
-    constexpr int ROWS = WP * 8, BC = WC * 64;
+    constexpr int ROWS = WP * TPW, BC = WC * 64, NWV = WP * WC;
     constexpr int HROWS = (ROWS + 2) * HWID;
-    constexpr int NLD = 8;
-    constexpr int NXW = ((HROWS + 15) / 16 + NLD - 1) / NLD;
-    const int smem = 2 * NXW * NLD * 16 * HB + NW * BC * HB + (XT ? a.Cin * 8 : 0);
+    constexpr int NXW = ((HROWS + 15) / 16 + NWV - 1) / NWV;
+    const int smem = 2 * NXW * NWV * 16 * HB + NW * BC * HB + (XT ? a.Cin * 8 : 0);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
-    auto kern = conv3x3_halo_kernel<WP, WC, XT>;
+    auto kern = conv3x3_halo_kernel<WP, WC, XT, TPW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -483,7 +508,7 @@ hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
     const long long tiles = (long long)((a.W + TW - 1) / TW) * ((a.H + ROWS - 1) / ROWS);
     const long long nblk = tiles * (a.Cout / BC) * a.batch;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), smem, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NWV), smem, s, a);
     return hipGetLastError();
 }
 
@@ -511,6 +536,9 @@ int vt_conv3x3_halo_tiles(int H, int W, int Cout) {
     return ((W + TW - 1) / TW) * ((H + rows - 1) / rows);
 }
 
+int g_halo_waves = 8;      // 8 or 16 waves per workgroup for the XT == 0 kernel (vt_set_flag(ctx, 3, v))
+void vt_conv3x3_halo_set_waves(int n) { g_halo_waves = n == 16 ? 16 : 8; }
+
 bool vt_conv3x3_halo_supported(int Cin, int Cout) { return Cin >= 32 && (Cin % 32) == 0 && (Cout % 128) == 0; }
 
 int vt_conv3x3_halo_config(const Conv3x3Args& a) {      // profile slots 3..8 = <tile, XT>
@@ -528,7 +556,10 @@ hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
     const int xt = a.scale_shift ? (a.Xf32 ? 1 : 2) : 0;
     if (xt == 1 ? (a.X != nullptr) : (a.X == nullptr || a.Xf32 != nullptr)) return hipErrorInvalidValue;
     const bool big = (a.Cout % 256) == 0;                   // 16x16 px x 256 couts, else 32x16 px x 128 couts
-    if (xt == 0) return big ? launch<2, 4, 0>(a, s) : launch<4, 2, 0>(a, s);
-    if (xt == 1) return big ? launch<2, 4, 1>(a, s) : launch<4, 2, 1>(a, s);
-    return big ? launch<2, 4, 2>(a, s) : launch<4, 2, 2>(a, s);
+    if (xt == 0) {
+        if (g_halo_waves == 16) return big ? launch<4, 4, 0, 4>(a, s) : launch<8, 2, 0, 4>(a, s);
+        return big ? launch<2, 4, 0, 8>(a, s) : launch<4, 2, 0, 8>(a, s);
+    }
+    if (xt == 1) return big ? launch<2, 4, 1, 8>(a, s) : launch<4, 2, 1, 8>(a, s);
+    return big ? launch<2, 4, 2, 8>(a, s) : launch<4, 2, 2, 8>(a, s);
 }

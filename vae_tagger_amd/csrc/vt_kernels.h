@@ -54,6 +54,7 @@ struct Conv3x3Args {
 int vt_conv3x3_halo_tiles(int H, int W, int Cout);
 int vt_conv_gemm_ptiles(int HWo, int Cout);
 bool vt_conv3x3_halo_supported(int Cin, int Cout);
+void vt_conv3x3_halo_set_waves(int n);   // 8 (default) or 16 waves per workgroup
 int vt_conv3x3_halo_config(const Conv3x3Args& a);
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s);
 hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w_ohwi, bf16_t* wp, int Cin, int Cout, hipStream_t s);
