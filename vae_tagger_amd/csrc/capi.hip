@@ -144,7 +144,7 @@ int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, C
         for (int o = 0; o < cout; ++o)
             for (int t = 0; t < 9; ++t)
                 for (int i = 0; i < cin; ++i)
-                    hp[(((size_t)(i >> 5) * 9 + t) * cout + o) * 32 + (i & 31)] = p[((size_t)o * 9 + t) * cin + i];
+                    hp[(((size_t)(i >> 5) * 9 + t) * cout + ((o & ~63) + vt_halo_row_of_cout(o & 63))) * 32 + (i & 31)] = p[((size_t)o * 9 + t) * cin + i];
         out->wp = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
         if (!out->wp) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
     }

@@ -445,49 +445,46 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
     for (int chunk = 0; chunk + 1 < nchunk; ++chunk) do_chunk(chunk, std::false_type{});
     do_chunk(nchunk - 1, std::true_type{});
 
-#ifdef EXP_STAMP
-    unsigned long long Tk1; STAMP(Tk1);
-#endif
-    // ---- epilogue: lane holds couts cg..cg+3 of pixel (y, x) for every (i, j)
+    // ---- epilogue.  Weight rows are packed so that MFMA tile i / accumulator register r of lane (fq, fr) is
+    // cout cw + 16*fq + 4*i + r: a lane owns 16 CONSECUTIVE couts of pixel (y, x = tx0 + fr) -> 16-B stores, and the
+    // four fq lanes of a pixel cover one full 128-B (bf16) / 256-B (fp32) line per wave.
     const int HWp = a.H * a.W;
     const long long ob = (long long)b * HWp * a.Cout;
     const int x = tx0 + fr;
+    const int cw = c0 + wc * 64 + 16 * fq;               // first of this lane's 16 couts
+    f32x4 bv[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) bv[i] = a.bias ? *(const f32x4*)(a.bias + cw + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned valid = 0;
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int y = ty0 + wp * TPW + j;
         if (y >= a.H || x >= a.W) continue;
         valid |= 1u << j;
-        const long long p = (long long)y * a.W + x;
+        const long long o = ob + ((long long)y * a.W + x) * a.Cout + cw;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
-            const int cg = c0 + wc * 64 + i * 16 + fq * 4;
-            f32x4 v = acc[i][j];
-            if (a.bias) v += *(const f32x4*)(a.bias + cg);
-            const long long o = ob + p * a.Cout + cg;
-            if (a.res) v += *(const f32x4*)(a.res + o);
-            if (a.out_f32) *(f32x4*)(a.out_f32 + o) = v;
-            if (a.out_bf16) {
-                bf16x4 h;
-                h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
-                *(bf16x4*)(a.out_bf16 + o) = h;
-            }
+            f32x4 v = acc[i][j] + bv[i];
+            if (a.res) v += *(const f32x4*)(a.res + o + 4 * i);
+            if (a.out_f32) *(f32x4*)(a.out_f32 + o + 4 * i) = v;
             acc[i][j] = v;
         }
+        if (a.out_bf16) {
+#pragma unroll
+            for (int i = 0; i < TC; i += 2) {
+                bf16x8 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { h[r] = (bf16_t)acc[i][j][r]; h[4 + r] = (bf16_t)acc[i + 1][j][r]; }
+                *(bf16x8*)(a.out_bf16 + o + 4 * i) = h;
+            }
+        }
     }
-#ifdef EXP_STAMP
-    if (a.dbg && lane == 0) {
-        unsigned long long Tk2; STAMP(Tk2);
-        unsigned long long* d = a.dbg + ((long long)blockIdx.x * 8 + wave) * 8;
-        d[0] = dsum[0]; d[1] = dsum[1]; d[2] = dsum[2]; d[3] = dsum[3]; d[4] = dsum[4]; d[5] = Tk1 - Tk0; d[6] = Tk2 - Tk1;
-    }
-#endif
     if (a.gn_partial) {
         // GroupNorm statistics of this tile's outputs for the NEXT layer's norm (replaces a full read pass)
         __syncthreads();                                   // every wave is done with the staging LDS
         const int G = a.Cout / a.gn_cpg;
         float* out = a.gn_partial + (((long long)b * (tiles_x * tiles_y) + tile) * G + c0 / a.gn_cpg) * 3;
-        vt_gn_epilogue_partials<TC, TP>(acc, valid, a.gn_cpg, wp, WP, wc * 64, BC, (float*)smem, out);
+        vt_gn_epilogue_partials_il<TC, TP>(acc, valid, a.gn_cpg, wp, WP, wc * 64, BC, (float*)smem, out);
     }
 }
 
@@ -520,7 +517,8 @@ __global__ void repack_ohwi_kernel(const bf16_t* __restrict__ w, bf16_t* __restr
     const int ci = (int)(i % Cin);
     const int tap = (int)((i / Cin) % 9);
     const int co = (int)(i / ((long long)Cin * 9));
-    wp[(((long long)(ci >> 5) * 9 + tap) * Cout + co) * 32 + (ci & 31)] = w[i];
+    const int row = (co & ~63) + vt_halo_row_of_cout(co & 63);      // interleaved cout map (see the kernel epilogue)
+    wp[(((long long)(ci >> 5) * 9 + tap) * Cout + row) * 32 + (ci & 31)] = w[i];
 }
 
 }  // namespace

@@ -106,3 +106,62 @@ __device__ __forceinline__ void vt_gn_epilogue_partials(const f32x4 (&v)[TC][TP]
         o[0] = n; o[1] = mean; o[2] = m2;
     }
 }
+
+// Variant for the "interleaved" cout map of conv3x3_halo: a lane's registers hold 16 CONSECUTIVE couts of its pixel,
+// cout = wave_cout0 + 16*fq + 4*i + r (tile i, register r), so every GroupNorm group (4, 8 or 16 channels) lives in
+// ONE lane; only the 16 pixel columns (fr) are merged across lanes.
+template <int TC, int TP>
+__device__ __forceinline__ void vt_gn_epilogue_partials_il(const f32x4 (&v)[TC][TP], unsigned valid, int cpg, int wp,
+                                                           int nwp, int wave_cout0, int block_couts, float* lds,
+                                                           float* out) {
+    static_assert(TC == 4, "interleaved map covers 16 couts per lane");
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int gpb = block_couts / cpg;
+    const float nl = 4.0f * (float)__popc(valid);
+    const int tpg = cpg >> 2;                      // tiles (4-cout register groups) per GroupNorm group: 1, 2 or 4
+#pragma unroll
+    for (int g0 = 0; g0 < TC; ++g0) {
+        if (g0 % tpg) continue;                    // g0 = first tile of a group
+        const float piv = __shfl(v[g0][0][0], lane & 48, 64);
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int i = g0; i < TC; ++i) {
+            if (i >= g0 + tpg) break;
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                if ((valid >> j) & 1u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float d = v[i][j][r] - piv; s += d; ss = fmaf(d, d, ss); }
+                }
+            }
+        }
+        float n = nl * (float)tpg;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); n += __shfl_xor(n, o, 64); }
+        float mean = 0.f, m2 = 0.f;
+        if (n > 0.f) { const float ms = s / n; mean = piv + ms; m2 = fmaxf(ss - s * ms, 0.f); }
+        if (fr == 0) {
+            const int lg = (wave_cout0 + 16 * fq + 4 * g0) / cpg;
+            float* d = lds + (wp * gpb + lg) * 3;
+            d[0] = n; d[1] = mean; d[2] = m2;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < gpb) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int w = 0; w < nwp; ++w) {
+            const float* d = lds + (w * gpb + threadIdx.x) * 3;
+            vt_chan_merge(n, mean, m2, d[0], d[1], d[2]);
+        }
+        float* o = out + threadIdx.x * 3;
+        o[0] = n; o[1] = mean; o[2] = m2;
+    }
+}
+
+// LDS row (inside a wave's 64-cout group) that must hold cout_local, so that MFMA tile i / A-row r' lands on
+// cout_local = (r' & 3) + 4*i + 16*(r' >> 2).  Used by the host and device weight packers.
+__host__ __device__ inline int vt_halo_row_of_cout(int cout_local /*0..63*/) {
+    const int r = cout_local & 3, i = (cout_local >> 2) & 3, q = cout_local >> 4;
+    return 16 * i + 4 * q + r;
+}
