@@ -45,6 +45,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--generic-conv", action="store_true", help="A/B: disable the halo-tile 3x3 kernel")
     p.add_argument("--cpu-sample-res", type=int, default=1024)
+    p.add_argument("--no-occ2", action="store_true", help="A/B: 128-cout convs on the one-workgroup-per-CU tile")
     return p.parse_args()
 
 
@@ -94,6 +95,10 @@ def main():
     from vae_tagger_amd.modules import create_attention_decoder
     from vae_tagger_amd.pipeline import EncodeTagPipeline
 
+    # the mirrors print the reference's construction messages; stdout carries the ONE JSON line only
+    import contextlib
+    _quiet = contextlib.redirect_stdout(sys.stderr)
+    _quiet.__enter__()
     vae = load_diffusers_vae_from_config(get_diffusers_vae_config())
     vae.load_state_dict(synth.synth_state_dict(synth.encoder_manifest(), seed=0), strict=False)
     vae_model = DiffusersVAEWrapper(vae).to(dev).eval()
@@ -103,8 +108,11 @@ def main():
     dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(a.tags), seed=1), strict=False)
     dec = dec.to(dev).eval()
     pipe = EncodeTagPipeline(vae_model, dec)
+    _quiet.__exit__(None, None, None)
     if a.generic_conv:
         pipe.ctx.call("vt_set_flag", 0, 0)
+    if a.no_occ2:
+        pipe.ctx.call("vt_set_flag", 3, 0)
 
     B = a.batch
     counts = [B] * world

@@ -89,10 +89,10 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         0 = every GroupNorm runs its own statistics pass.
  * flag 2: 1 = GroupNorm-apply + SiLU in front of a 3x3 stride-1 conv runs inside that conv's halo staging,
  *         0 (default) = as a standalone HBM-bound pass (one read + one bf16 write of the tensor).
+ * flag 3: 1 (default) = 128-cout 3x3 convs use the 16x16-pixel tile that lets two workgroups share a CU,
+ *         0 = the 32x16-pixel one-workgroup-per-CU tile (process-wide).
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
-/* diagnostic (EXP_STAMP) builds only: device buffer that receives per-wave phase cycle counts; NULL otherwise */
-int vt_set_debug_buffer(void* device_ptr);
 
 /* ---- measurement ----------------------------------------------------------------------------
  * Between vt_profile_begin and vt_profile_end every launch of the implicit-GEMM MFMA kernel is

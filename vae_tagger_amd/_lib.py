@@ -36,7 +36,6 @@ PROTOTYPES = {
     "vt_preprocess_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "vt_encoder_flops": (_c.c_double, [_vp, _i, _i]),
     "vt_set_flag": (_i, [_vp, _i, _i]),
-    "vt_set_debug_buffer": (_i, [_vp]),
     "vt_profile_num_configs": (_i, []),
     "vt_profile_begin": (_i, [_vp]),
     "vt_profile_end": (_i, [_vp, _i, _c.POINTER(_ll), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_char_p)]),

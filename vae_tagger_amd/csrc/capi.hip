@@ -263,7 +263,7 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
         h.X = xnorm_f32 ? nullptr : x; h.Xf32 = xnorm_f32; h.scale_shift = ss;
         h.Wp = w.wp; h.bias = w.b; h.res = res; h.out_f32 = o32; h.out_bf16 = o16; h.zeros = c->zeros;
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
-        if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout); }
+        if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout, ss != nullptr); }
         HIPCK(c, launch_halo(c, h, s), "conv3x3_halo");
         return VT_OK;
     }
@@ -387,7 +387,7 @@ EncPlan plan_encoder(const EncoderW& e, int B, int H, int W) {
         if (n > p.max_elems) p.max_elems = n;
         if (ch > p.max_c) p.max_c = ch;
         int ck = vt_gn_max_chunks(hh * ww, ch);
-        const int t1 = vt_conv_gemm_ptiles(hh * ww, ch), t2 = vt_conv3x3_halo_tiles(hh, ww, ch), t3 = vt_conv_in_parts(hh, ww);
+        const int t1 = vt_conv_gemm_ptiles(hh * ww, ch), t2 = vt_conv3x3_halo_tiles(hh, ww, ch, 0), t3 = vt_conv_in_parts(hh, ww);
         if (t3 > ck) ck = t3;
         if (t1 > ck) ck = t1;
         if (t2 > ck) ck = t2;
@@ -822,7 +822,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 0) { c->use_halo_conv = value != 0; return VT_OK; }
     if (flag == 1) { c->fuse_gn_stats = value != 0; return VT_OK; }
     if (flag == 2) { c->fuse_gn_apply = value != 0; return VT_OK; }
-    if (flag == 3) { vt_conv3x3_halo_set_waves(value); return VT_OK; }      // process-wide: halo kernel geometry
+    if (flag == 3) { vt_conv3x3_halo_set_occ2(value); return VT_OK; }       // process-wide: halo kernel geometry
     return c->fail(VT_ERR_INVALID, "vt_set_flag: unknown flag %d", flag);
 }
 
@@ -858,9 +858,6 @@ int vt_profile_end(vt_context* c, int max_cfg, long long* launches, double* tota
 }
 
 // ---- single operators ---------------------------------------------------------------------------
-void* g_vt_dbg = nullptr;   // diagnostic builds: set through vt_set_debug_buffer
-extern "C" int vt_set_debug_buffer(void* p) { g_vt_dbg = p; return 0; }
-
 int vt_op_conv2d(vt_context* c, const void* x, const void* w, const float* bias, const float* res, float* o32, void* o16,
                  int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int pad_lo, int pad_hi, void* stream) {
     if (!c) return VT_ERR_INVALID;
@@ -880,7 +877,6 @@ int vt_op_conv2d(vt_context* c, const void* x, const void* w, const float* bias,
         Conv3x3Args h{};
         h.X = (const bf16_t*)x; h.Wp = (const bf16_t*)c->op_scratch; h.bias = bias; h.res = res; h.out_f32 = o32;
         h.out_bf16 = (bf16_t*)o16; h.zeros = c->zeros; h.batch = B; h.H = Hin; h.W = Win; h.Cin = Cin; h.Cout = Cout;
-        h.dbg = (unsigned long long*)g_vt_dbg;
         HIPCK(c, launch_halo(c, h, (hipStream_t)stream), "vt_op_conv2d(halo)");
         return VT_OK;
     }
@@ -922,7 +918,7 @@ int vt_op_norm_silu_conv3x3(vt_context* c, const void* x, int x_dtype, const flo
 size_t vt_op_conv2d_gn_workspace_bytes(int B, int Hout, int Wout, int Cout) {
     if (B <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0) return 0;
     int parts = vt_conv_gemm_ptiles(Hout * Wout, Cout);
-    const int t2 = vt_conv3x3_halo_tiles(Hout, Wout, Cout);
+    const int t2 = vt_conv3x3_halo_tiles(Hout, Wout, Cout, 0);
     if (t2 > parts) parts = t2;
     return align_up((size_t)B * parts * 64 * 3 * 4);
 }

@@ -26,7 +26,7 @@ namespace {
 constexpr int HB = 64;        // bytes per LDS row (32 bf16)
 constexpr int TW = 16;        // tile width in pixels (one MFMA column block)
 constexpr int HWID = TW + 2;  // halo width
-constexpr int NW = 6;         // weight ring depth
+constexpr int NW_DEFAULT = 6;  // weight ring depth of the 1-workgroup-per-CU variants
 
 __device__ __forceinline__ void wait_vmcnt(int n) {
     switch (n) {
@@ -50,11 +50,6 @@ __device__ __forceinline__ void wait_vmcnt_tied(int n, V& r0, V& r1) {
     }
 }
 
-#ifdef EXP_STAMP
-#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define STAMP(v) do { } while (0)
-#endif
 
 // Identity the optimiser cannot see through: stops loop-invariant address arithmetic built on `v` from being
 // hoisted into (and spilled from) long-lived registers -- it is recomputed where it is used instead.
@@ -79,13 +74,15 @@ __device__ __forceinline__ void wait_vmcnt_tied1(int n, V& r0) {
 //      hand-counted inline-asm global loads, GroupNorm'ed with the per-(image, channel) (scale, shift) the
 //      previous layer's epilogue statistics produced, SiLU'ed, rounded to bf16 and written to LDS -- the
 //      standalone GroupNorm+SiLU pass (one read + one write of the whole tensor) disappears.
-// TPW = tile rows per wave: 8 with 8 waves (2 per SIMD, <= 256 VGPRs), 4 with 16 waves (4 per SIMD, <= 128 VGPRs:
-// twice the instruction streams per SIMD to fill each other's non-MFMA gaps).
-template <int WP, int WC, int XT, int TPW>
-__global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x3Args a) {
+// TPW = tile rows per wave: 8 (wave tile 128 px x 64 couts, <= 256 VGPRs, one workgroup per CU) or 4 (see OCC2 below).
+// NW = weight ring depth.  OCC2 variants (8 waves x 4 rows, NW = 4): <= 128 VGPRs and <= 80 KB LDS so TWO workgroups
+// share a CU -- one streams its epilogue to HBM (per-CU store rate ~25 GB/s, ~30 us per tile) while the other computes.
+template <int WP, int WC, int XT, int TPW, int NW>
+__global__ __launch_bounds__(64 * WP * WC, TPW == 4 ? 4 : 2)
+void conv3x3_halo_kernel(const Conv3x3Args a) {
     constexpr int NWV = WP * WC;                 // waves per workgroup
     constexpr int NT = 64 * NWV;
-    static_assert((NWV == 8 && TPW == 8) || (NWV == 16 && TPW == 4 && XT == 0), "8 waves x 8 rows or 16 waves x 4 rows");
+    static_assert(NWV == 8 && (TPW == 8 || (TPW == 4 && XT == 0)), "8 waves x 8 rows, or 8 waves x 4 rows (two workgroups per CU)");
     constexpr int ROWS = WP * TPW;               // tile rows (each wave: TPW rows x 16 px)
     constexpr int BC = WC * 64;                  // couts per workgroup (each wave: 64)
     constexpr int TP = TPW, TC = 4;
@@ -210,14 +207,10 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
             }
             const f32x4 q0 = *(const f32x4*)(sp + hh * 8), q1 = *(const f32x4*)(sp + hh * 8 + 4);   // (scale, shift) x 4 ch
             bf16x4 o;
-#ifdef EXP_NOMATH
-            o[0] = (bf16_t)(v[0] + q0[0]); o[1] = (bf16_t)(v[1] + q0[2]); o[2] = (bf16_t)(v[2] + q1[0]); o[3] = (bf16_t)(v[3] + q1[2]);
-#else
             o[0] = (bf16_t)vt_silu(fmaf(v[0], q0[0], q0[1]));
             o[1] = (bf16_t)vt_silu(fmaf(v[1], q0[2], q0[3]));
             o[2] = (bf16_t)vt_silu(fmaf(v[2], q1[0], q1[1]));
             o[3] = (bf16_t)vt_silu(fmaf(v[3], q1[2], q1[3]));
-#endif
             if (pad) o = bf16x4{0, 0, 0, 0};
             *(bf16x4*)(dst + hh * 8) = o;
         }
@@ -231,23 +224,11 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
     // The swizzle bit of row hr is bit 2 of (R + fr), a function of (R & 7, fr) only, and R & 7 =
     // ((j+dy)*18 + dx) & 7 is a compile-time constant (wp*144 is a multiple of 8).  So 8 per-lane base
     // addresses (one per value of R & 7) plus ds_read immediate offsets cover all 72 (tap, j) reads.
-    // 8-wave variants keep the 8 addresses in registers; the 16-wave variants (128-VGPR budget) keep one base
-    // address plus an 8-bit per-lane mask and rebuild the address with 2 VALU ops per read.
-    constexpr bool XSEL_REGS = true;   // (rebuilding the address per read made the 16-wave variants spill more, not less)
-    int xsel[XSEL_REGS ? 8 : 1];
-    const int xa0 = (wp * TPW * HWID + fr) * HB + (fq << 4);
-    int xmask8 = 0;
+    int xsel[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int bit = ((k + fr) >> 2) & 1;
-        if constexpr (XSEL_REGS) xsel[k] = xa0 ^ (bit << 5);
-        xmask8 |= bit << k;
-    }
-    if constexpr (!XSEL_REGS) xsel[0] = 0;
-    auto xaddr = [&](int k) -> int {                       // k is a compile-time constant after unrolling
-        if constexpr (XSEL_REGS) return xsel[k];
-        else return opaque(xa0) ^ (((xmask8 >> k) & 1) << 5);
-    };
+    for (int k = 0; k < 8; ++k)
+        xsel[k] = (wp * TPW * HWID + fr) * HB + ((fq ^ ((((k + fr) >> 2) & 1) << 1)) << 4);
+    auto xaddr = [&](int k) -> int { return xsel[k]; };        // k is a compile-time constant after unrolling
     f32x4 acc[TC][TP];
 #pragma unroll
     for (int i = 0; i < TC; ++i)
@@ -271,10 +252,11 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
         }
     }
     // SPF (software-pipelined fragments, XT == 0): the MFMA operands of step t+1 are read from LDS DURING step t
-    // (a second W-fragment register set; each X fragment is refilled as soon as its last MFMA has issued), so
-    // after a barrier the matrix pipe starts at once instead of waiting ~250 cycles for 12 ds_read_b128.  That
-    // needs W(t+1) landed at the barrier of step t: the ring is filled one step further ahead (W(t+NW) is issued
-    // at step t into the stage whose fragments were read during step t-1).
+    // (each X fragment is refilled as soon as its last MFMA has issued; the W fragments, live until the last MFMA,
+    // are refilled at the end of the step and fly during the barrier wait), so after a barrier the matrix pipe
+    // starts at once instead of waiting for 12 ds_read_b128.  That needs W(t+1) landed at the barrier of step t:
+    // the ring is filled one step further ahead (W(t+NW) is issued at step t into the stage whose fragments were
+    // read during step t-1).
     constexpr bool SPF = XT == 0;
     constexpr int LEAD = SPF ? NW : NW - 1;      // W(t + LEAD) is issued at step t
 #pragma unroll
@@ -282,10 +264,6 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
         if (t < nk) issue_w(t);
 
     bf16x8 wfc[TC], xfr[TP];                     // SPF: fragments of the step about to run
-#ifdef EXP_STAMP
-    unsigned long long dsum[5] = {0, 0, 0, 0, 0};
-    unsigned long long Tk0; STAMP(Tk0);
-#endif
     if constexpr (SPF) {
         int ahead0 = nk - 1;
         if (ahead0 > NW - 1) ahead0 = NW - 1;
@@ -316,8 +294,6 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int t = tbase + tap;
-            [[maybe_unused]] unsigned long long T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0;
-            STAMP(T0);
             // the operand needed at this barrier: W(t) -- or W(t+1) with SPF, whose fragments are read during
             // this step.  Ops issued after it: the next NW-2 weight tiles (+ the next halo inside its window).
             if constexpr (!LAST) {
@@ -332,15 +308,12 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
                 wait_vmcnt(ahead * wpw);
             }
             if (XT != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's staged rows are written
-            STAMP(T1);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();        // all waves' pieces of the tile (and X(chunk)) are in LDS;
             asm volatile("" ::: "memory");       // everyone is done reading the stage that is refilled next
-            STAMP(T2);
             if constexpr (!SPF) {
                 if (!LAST || t + LEAD < nk) issue_w(t + LEAD);
             }
-            STAMP(T3);
 
             if constexpr (SPF) {
                 // MFMAs of step t on registers filled during step t-1; meanwhile fetch step t+1's fragments
@@ -354,12 +327,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
                 // wave slips its pieces into the MIDDLE of its MFMA sequence.  The older wave of a SIMD pair wins MFMA
                 // arbitration and reaches that point ~200 cycles before its partner, so one wave's DMA issue runs
                 // beside the other's MFMAs.
-#if defined(EXP_PRIO_NONE)
-#elif defined(EXP_PRIO_YOUNG)
-                if (early) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
-#else
                 __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
 #pragma unroll
@@ -380,10 +348,6 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
 #pragma unroll
                     for (int i = 0; i < TC; ++i) wfc[i] = *(const bf16x8*)(ws_n + i * 16 * HB);
                 }
-#ifdef EXP_STAMP
-                STAMP(T4);
-                dsum[0] += T1 - T0; dsum[1] += T2 - T1; dsum[2] += T3 - T2; dsum[3] += T4 - T3; dsum[4] += 1;
-#endif
                 continue;
             }
             const char* ws = wbase + (t % NW) * WBUF + opaque(wfoff);     // stage bases beyond 64 KB cannot be ds_read immediates
@@ -401,10 +365,8 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
             auto stage_row = [&]() {
                 int n = DLY * wpw;                // W issued in steps r+1 .. tap (this step's W is already out)
                 for (int q = r + 1; q < tap; ++q) if (q < NXW) n += LX;          // rows r+1 .. tap-1
-#ifndef EXP_NOWAIT
                 if constexpr (XT == 1) wait_vmcnt_tied(n, rq[r % DLY][0], rq[r % DLY][1]);
                 else wait_vmcnt_tied1(n, rq[r % DLY][0]);
-#endif
                 write_row(r, chunk + 1, rq[r % DLY][0], rq[r % DLY][XT == 1 ? 1 : 0]);
             };
             if constexpr (STAGE) {
@@ -436,9 +398,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
                 }
                 // load row `tap` of the next chunk into the slot just freed.  VM issue order stays
                 // W(t+NW-1) -> row `tap` -> W(t+NW).
-#ifndef EXP_NOLOAD
                 if (tap < NXW) load_row(tap, chunk + 1, rq[tap % DLY][0], rq[tap % DLY][XT == 1 ? 1 : 0]);
-#endif
             }
         }
     };
@@ -488,7 +448,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv3x3_halo_kernel(const Conv3x
     }
 }
 
-template <int WP, int WC, int XT, int TPW>
+template <int WP, int WC, int XT, int TPW, int NW = NW_DEFAULT>
 hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
     constexpr int ROWS = WP * TPW, BC = WC * 64, NWV = WP * WC;
     constexpr int HROWS = (ROWS + 2) * HWID;
@@ -496,7 +456,7 @@ hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
     const int smem = 2 * NXW * NWV * 16 * HB + NW * BC * HB + (XT ? a.Cin * 8 : 0);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
-    auto kern = conv3x3_halo_kernel<WP, WC, XT, TPW>;
+    auto kern = conv3x3_halo_kernel<WP, WC, XT, TPW, NW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -529,13 +489,17 @@ hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w, bf16_t* wp, int Cin, i
     return hipGetLastError();
 }
 
-int vt_conv3x3_halo_tiles(int H, int W, int Cout) {
-    const int rows = (Cout % 256) == 0 ? 16 : 32;
+int g_halo_occ2 = 1;       // 128-cout layers use the 2-workgroups-per-CU tile (vt_set_flag(ctx, 3, 0) turns it off)
+
+int vt_conv3x3_halo_tiles(int H, int W, int Cout, int fused_norm) {
+    // must match the tile the dispatcher below picks: 256-cout tiles have 16 rows; 128-cout tiles 16 rows in the
+    // two-workgroups-per-CU variant (plain bf16 input only) and 32 rows otherwise
+    const int rows = (Cout % 256) == 0 ? 16 : ((g_halo_occ2 && !fused_norm) ? 16 : 32);
     return ((W + TW - 1) / TW) * ((H + rows - 1) / rows);
 }
 
-int g_halo_waves = 8;      // 8 or 16 waves per workgroup for the XT == 0 kernel (vt_set_flag(ctx, 3, v))
-void vt_conv3x3_halo_set_waves(int n) { g_halo_waves = n == 16 ? 16 : 8; }
+void vt_conv3x3_halo_set_occ2(int on) { g_halo_occ2 = on != 0; }
+int vt_conv3x3_halo_occ2(void) { return g_halo_occ2; }
 
 bool vt_conv3x3_halo_supported(int Cin, int Cout) { return Cin >= 32 && (Cin % 32) == 0 && (Cout % 128) == 0; }
 
@@ -555,7 +519,7 @@ hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
     if (xt == 1 ? (a.X != nullptr) : (a.X == nullptr || a.Xf32 != nullptr)) return hipErrorInvalidValue;
     const bool big = (a.Cout % 256) == 0;                   // 16x16 px x 256 couts, else 32x16 px x 128 couts
     if (xt == 0) {
-        if (g_halo_waves == 16) return big ? launch<4, 4, 0, 4>(a, s) : launch<8, 2, 0, 4>(a, s);
+        if (g_halo_occ2 && !big) return launch<4, 2, 0, 4, 4>(a, s);           // 16x16 px x 128 couts, 2 workgroups / CU
         return big ? launch<2, 4, 0, 8>(a, s) : launch<4, 2, 0, 8>(a, s);
     }
     if (xt == 1) return big ? launch<2, 4, 1, 8>(a, s) : launch<4, 2, 1, 8>(a, s);

@@ -270,9 +270,10 @@ int vt_conv_gemm_ptiles(int HWo, int Cout) {
 int vt_conv_gemm_config(const ConvGemmArgs& a) { return a.Cout <= 32 ? 0 : (a.Cout <= 128 ? 1 : 2); }
 const char* vt_conv_gemm_config_name(int cfg) {
     static const char* n[VT_NUM_PROF_SLOTS] = {"conv_gemm_kernel<128,32,8,1>", "conv_gemm_kernel<256,128,4,2>",
-                                               "conv_gemm_kernel<256,256,2,4>", "conv3x3_halo_kernel<4,2,0>",
-                                               "conv3x3_halo_kernel<2,4,0>", "conv3x3_halo_kernel<4,2,1>",
-                                               "conv3x3_halo_kernel<2,4,1>", "conv3x3_halo_kernel<4,2,2>",
-                                               "conv3x3_halo_kernel<2,4,2>", "gn_apply_kernel"};
+                                               "conv_gemm_kernel<256,256,2,4>", "conv3x3_halo_kernel<4,2,0,4,4>",
+                                               "conv3x3_halo_kernel<2,4,0,8,6>", "conv3x3_halo_kernel<4,2,1,8,6>",
+                                               "conv3x3_halo_kernel<2,4,1,8,6>", "conv3x3_halo_kernel<4,2,2,8,6>",
+                                               "conv3x3_halo_kernel<2,4,2,8,6>", "gn_apply_kernel"};
+    if (cfg == 3 && !vt_conv3x3_halo_occ2()) return "conv3x3_halo_kernel<4,2,0,8,6>";
     return (cfg >= 0 && cfg < VT_NUM_PROF_SLOTS) ? n[cfg] : "?";
 }

@@ -49,12 +49,12 @@ struct Conv3x3Args {
     float* gn_partial;      // optional [batch][tiles][Cout/gn_cpg][3] (n, mean, M2) of the output values
     int gn_cpg;             // channels per GroupNorm group of the OUTPUT (4, 8 or 16)
     int batch, H, W, Cin, Cout;
-    unsigned long long* dbg; // diagnostic builds only (EXP_STAMP): per-wave phase cycle sums
 };
-int vt_conv3x3_halo_tiles(int H, int W, int Cout);
+int vt_conv3x3_halo_tiles(int H, int W, int Cout, int fused_norm);   // GroupNorm partials per image the epilogue writes
 int vt_conv_gemm_ptiles(int HWo, int Cout);
 bool vt_conv3x3_halo_supported(int Cin, int Cout);
-void vt_conv3x3_halo_set_waves(int n);   // 8 (default) or 16 waves per workgroup
+void vt_conv3x3_halo_set_occ2(int on);   // 128-cout layers: 2-workgroups-per-CU tile (default on)
+int vt_conv3x3_halo_occ2(void);
 int vt_conv3x3_halo_config(const Conv3x3Args& a);
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s);
 hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w_ohwi, bf16_t* wp, int Cin, int Cout, hipStream_t s);
