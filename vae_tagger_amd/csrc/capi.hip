@@ -306,20 +306,31 @@ int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const float* x3
     return run_conv(c, w, x16, B, H, W, 1, 1, H, W, res, o32, o16, s, want_stats ? &gn : nullptr, groups, x32, gn.ss);
 }
 
-struct AttnScratch { bf16_t* qk; bf16_t* vt; float* scores; bf16_t* probs; bf16_t* o; };
+struct AttnScratch { bf16_t* qk; bf16_t* vt; f16_t* scores; bf16_t* probs; bf16_t* o; int group; };
 
-size_t attn_scratch_bytes(int B, int S, int C) {
+// Scores and probabilities are materialised for `group` images at a time (one batched launch each for Q.K^T,
+// softmax and P.V): as many images as fit an 8 GiB budget (1 GiB per image at S = 16384).
+int attn_group(int B, int S) {
     const size_t ld = (size_t)(S + 7) / 8 * 8;
-    return align_up((size_t)B * S * 2 * C * 2) + align_up((size_t)B * C * ld * 2) + align_up((size_t)S * ld * 4) +
-           align_up((size_t)S * ld * 2) + align_up((size_t)B * S * C * 2);
+    const size_t per_img = (size_t)S * ld * 4;                      // fp16 scores + bf16 probs
+    size_t g = ((size_t)8 << 30) / (per_img ? per_img : 1);
+    if (g < 1) g = 1;
+    if (g > (size_t)B) g = (size_t)B;
+    return (int)g;
+}
+size_t attn_scratch_bytes(int B, int S, int C) {
+    const size_t ld = (size_t)(S + 7) / 8 * 8, G = (size_t)attn_group(B, S);
+    return align_up((size_t)B * S * 2 * C * 2) + align_up((size_t)B * C * ld * 2) + align_up(G * S * ld * 2) +
+           align_up(G * S * ld * 2) + align_up((size_t)B * S * C * 2);
 }
 AttnScratch carve_attn(char* p, int B, int S, int C) {
-    const size_t ld = (size_t)(S + 7) / 8 * 8;
+    const size_t ld = (size_t)(S + 7) / 8 * 8, G = (size_t)attn_group(B, S);
     AttnScratch a;
+    a.group = (int)G;
     a.qk = (bf16_t*)p; p += align_up((size_t)B * S * 2 * C * 2);
     a.vt = (bf16_t*)p; p += align_up((size_t)B * C * ld * 2);
-    a.scores = (float*)p; p += align_up((size_t)S * ld * 4);
-    a.probs = (bf16_t*)p; p += align_up((size_t)S * ld * 2);
+    a.scores = (f16_t*)p; p += align_up(G * S * ld * 2);
+    a.probs = (bf16_t*)p; p += align_up(G * S * ld * 2);
     a.o = (bf16_t*)p;
     return a;
 }
@@ -342,17 +353,19 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const float*
     a.Win = a.Wout = C; a.Cin = C; a.Cout = ld; a.Wrows = S; a.ldx = C; a.ldw = C; a.ldo = ld;
     a.x_bs = 0; a.w_bs = (long long)S * C; a.o_bs = (long long)C * ld; a.batch = B;
     HIPCK(c, launch_gemm(c, a, s), "attn v proj");
-    for (int b = 0; b < B; ++b) {
-        const bf16_t* q = sc.qk + (long long)b * S * 2 * C;
-        // scores = q k^T / sqrt(C) -> fp32 [S][ld]
-        a.X = q; a.W = q + C; a.bias = nullptr; a.bias_mode = 0; a.out_bf16 = nullptr; a.out_f32 = sc.scores;
+    for (int b0 = 0; b0 < B; b0 += sc.group) {
+        const int nb = (B - b0 < sc.group) ? B - b0 : sc.group;
+        const bf16_t* q = sc.qk + (long long)b0 * S * 2 * C;
+        // scores = q k^T / sqrt(C) -> fp16 [nb][S][ld]   (|s| is O(1): fp16's 2^-11 is far below the bf16 rounding of P)
+        a.X = q; a.W = q + C; a.bias = nullptr; a.bias_mode = 0; a.out_bf16 = nullptr; a.out_f32 = nullptr; a.out_f16 = sc.scores;
         a.Win = a.Wout = S; a.Cin = C; a.Cout = ld; a.Wrows = S; a.ldx = 2 * C; a.ldw = 2 * C; a.ldo = ld;
-        a.x_bs = a.w_bs = a.o_bs = 0; a.batch = 1; a.alpha = 1.0f / sqrtf((float)C);
+        a.x_bs = a.w_bs = (long long)S * 2 * C; a.o_bs = (long long)S * ld; a.batch = nb; a.alpha = 1.0f / sqrtf((float)C);
         HIPCK(c, launch_gemm(c, a, s), "attn scores");
-        HIPCK(c, vt_launch_softmax_rows(sc.scores, sc.probs, S, S, ld, ld, s), "attn softmax");
-        // o = P v -> bf16 [S][C]
-        a.X = sc.probs; a.W = sc.vt + (long long)b * C * ld; a.out_f32 = nullptr; a.out_bf16 = sc.o + (long long)b * S * C;
+        HIPCK(c, vt_launch_softmax_rows(sc.scores, 1, sc.probs, (long long)nb * S, S, ld, ld, s), "attn softmax");
+        // o = P v -> bf16 [nb][S][C]
+        a.X = sc.probs; a.W = sc.vt + (long long)b0 * C * ld; a.out_f16 = nullptr; a.out_bf16 = sc.o + (long long)b0 * S * C;
         a.Cin = ld; a.Cout = C; a.Wrows = C; a.ldx = ld; a.ldw = ld; a.ldo = C; a.alpha = 1.f;
+        a.x_bs = (long long)S * ld; a.w_bs = (long long)C * ld; a.o_bs = (long long)S * C;
         HIPCK(c, launch_gemm(c, a, s), "attn pv");
     }
     // out = o Wo^T + bo + residual -> fp32 [B][S][C]
@@ -1008,7 +1021,7 @@ int vt_op_groupnorm(vt_context* c, const void* x, int x_dtype, int B, int HW, in
 
 int vt_op_softmax_rows(vt_context* c, const float* scores, void* probs, int rows, int n, int lds, int ldp, void* stream) {
     if (!c) return VT_ERR_INVALID;
-    HIPCK(c, vt_launch_softmax_rows(scores, (bf16_t*)probs, rows, n, lds, ldp, (hipStream_t)stream), "vt_op_softmax_rows");
+    HIPCK(c, vt_launch_softmax_rows(scores, 0, (bf16_t*)probs, rows, n, lds, ldp, (hipStream_t)stream), "vt_op_softmax_rows");
     return VT_OK;
 }
 

@@ -206,6 +206,11 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const ConvGemmArgs a) {
                 h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
                 *(bf16x4*)(a.out_bf16 + ob + o) = h;
             }
+            if (a.out_f16) {
+                f16x4 h;
+                h[0] = (f16_t)v[0]; h[1] = (f16_t)v[1]; h[2] = (f16_t)v[2]; h[3] = (f16_t)v[3];
+                *(f16x4*)(a.out_f16 + ob + o) = h;
+            }
             acc[i][j] = v;
         }
     }

@@ -120,40 +120,43 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row softmax, fp32 in -> bf16 out (P operand of the P.V GEMM).  One workgroup per row; the row
-// (<= 64 KiB) is L2-resident across the three sweeps.  Pad columns [n, ldp) are written as zeros so
-// the GEMM's 8-element k-chunks never see garbage.
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
-                                                           int n, int lds, int ldp) {
+// Row softmax of the attention scores (fp32, or fp16 as the QK^T epilogue writes them) -> bf16 P, the operand of
+// the P.V GEMM.  One workgroup per row.  Pad columns [n, ldp) are written as zeros so the GEMM's 8-element
+// k-chunks never see garbage.
+template <typename T> __device__ __forceinline__ float sm_ld(const T* p, long long i) { return (float)p[i]; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ s, bf16_t* __restrict__ p, int n,
+                                                           int lds, int ldp) {
     __shared__ float red[8];
     const long long row = blockIdx.x;
-    const float* sr = s + row * lds;
+    const T* sr = s + row * lds;
     bf16_t* pr = p + row * ldp;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float m = -INFINITY;
-    for (int i = tid; i < n; i += 256) m = fmaxf(m, sr[i]);
+    for (int i = tid; i < n; i += 256) m = fmaxf(m, sm_ld(sr, i));
     m = wave_max(m);
     if (lane == 0) red[wv] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
-    for (int i = tid; i < n; i += 256) sum += __expf(sr[i] - m);
+    for (int i = tid; i < n; i += 256) sum += __expf(sm_ld(sr, i) - m);
     sum = wave_sum(sum);
     if (lane == 0) red[4 + wv] = sum;
     __syncthreads();
     sum = (red[4] + red[5]) + (red[6] + red[7]);
     const float inv = 1.0f / sum;
-    for (int i = tid; i < ldp; i += 256) pr[i] = (bf16_t)(i < n ? __expf(sr[i] - m) * inv : 0.f);
+    for (int i = tid; i < ldp; i += 256) pr[i] = (bf16_t)(i < n ? __expf(sm_ld(sr, i) - m) * inv : 0.f);
 }
 
-// Single-read variant: the whole row (n <= NV*1024 fp32) lives in registers -- one HBM read, one bf16 write.
-// Requires lds % 4 == 0 and ldp % 4 == 0.
-template <int NV>
-__global__ __launch_bounds__(256) void softmax_rows_cached_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
+// Single-read variant: the whole row (ldp <= NV*1024 values) lives in registers -- one HBM read, one bf16 write.
+// Requires lds % 4 == 0, ldp % 4 == 0 and aligned bases.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void softmax_rows_cached_kernel(const T* __restrict__ s, bf16_t* __restrict__ p,
                                                                   int n, int lds, int ldp) {
     __shared__ float red[8];
     const long long row = blockIdx.x;
-    const float* sr = s + row * lds;
+    const T* sr = s + row * lds;
     bf16_t* pr = p + row * ldp;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     f32x4 v[NV];
@@ -161,10 +164,12 @@ __global__ __launch_bounds__(256) void softmax_rows_cached_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int i = (k * 256 + tid) * 4;
-        if (i + 3 < n) v[k] = *(const f32x4*)(sr + i);
-        else {
+        if (i + 3 < n) {
+            if constexpr (sizeof(T) == 4) v[k] = *(const f32x4*)(sr + i);
+            else { const f16x4 h = *(const f16x4*)(sr + i); v[k] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}; }
+        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[k][r] = (i + r < n) ? sr[i + r] : -INFINITY;
+            for (int r = 0; r < 4; ++r) v[k][r] = (i + r < n) ? sm_ld(sr, i + r) : -INFINITY;
         }
         m = fmaxf(m, fmaxf(fmaxf(v[k][0], v[k][1]), fmaxf(v[k][2], v[k][3])));
     }
@@ -235,18 +240,25 @@ hipError_t vt_launch_conv_in(const float* x, const float* wp, const float* bias,
 
 int vt_conv_in_parts(int H, int W) { return ((W + CI_PIX - 1) / CI_PIX) * ((H + CI_ROWS - 1) / CI_ROWS); }
 
-hipError_t vt_launch_softmax_rows(const float* scores, bf16_t* probs, int rows, int n, int lds, int ldp,
-                                  hipStream_t s) {
-    if (!scores || !probs || rows <= 0 || n <= 0 || lds < n || ldp < n) return hipErrorInvalidValue;
+template <typename T>
+static hipError_t softmax_dispatch(const T* scores, bf16_t* probs, long long rows, int n, int lds, int ldp, hipStream_t s) {
     const bool vec = (lds % 4 == 0) && (ldp % 4 == 0) && (((uintptr_t)scores) % 16 == 0) && (((uintptr_t)probs) % 8 == 0);
     const int need = (ldp + 1023) / 1024;           // NV covers ldp so the pad columns are written too
-#define SMX(NV) hipLaunchKernelGGL((softmax_rows_cached_kernel<NV>), dim3(rows), dim3(256), 0, s, scores, probs, n, lds, ldp)
+    const dim3 grid((unsigned)rows);
+#define SMX(NV) hipLaunchKernelGGL((softmax_rows_cached_kernel<T, NV>), grid, dim3(256), 0, s, scores, probs, n, lds, ldp)
     if (vec && need <= 1) SMX(1);
     else if (vec && need <= 2) SMX(2);
     else if (vec && need <= 4) SMX(4);
     else if (vec && need <= 8) SMX(8);
     else if (vec && need <= 16) SMX(16);
-    else hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, scores, probs, n, lds, ldp);
+    else hipLaunchKernelGGL((softmax_rows_kernel<T>), grid, dim3(256), 0, s, scores, probs, n, lds, ldp);
 #undef SMX
     return hipGetLastError();
+}
+
+hipError_t vt_launch_softmax_rows(const void* scores, int scores_f16, bf16_t* probs, long long rows, int n, int lds, int ldp,
+                                  hipStream_t s) {
+    if (!scores || !probs || rows <= 0 || rows > 0x7fffffffLL || n <= 0 || lds < n || ldp < n) return hipErrorInvalidValue;
+    return scores_f16 ? softmax_dispatch((const f16_t*)scores, probs, rows, n, lds, ldp, s)
+                      : softmax_dispatch((const float*)scores, probs, rows, n, lds, ldp, s);
 }

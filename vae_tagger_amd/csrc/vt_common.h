@@ -7,6 +7,8 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define VT_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))

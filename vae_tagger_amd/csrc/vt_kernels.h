@@ -10,6 +10,7 @@ struct ConvGemmArgs {
     const float* res;       // optional fp32 residual, indexed like the output rows
     float* out_f32;         // optional fp32 output rows [p][ldo]
     bf16_t* out_bf16;       // optional bf16 output rows [p][ldo]
+    f16_t* out_f16;         // optional fp16 output rows [p][ldo] (attention scores)
     const void* zeros;      // >= 16 zero bytes in device memory (padding / tail source for the DMA)
     float* gn_partial;      // optional [batch][ptiles][Cout/gn_cpg][3] (n, mean, M2) of the output values
     int Hin, Win, Hout, Wout;
@@ -80,9 +81,9 @@ hipError_t vt_launch_gn_apply(const void* x, int x_is_f32, const float* scale_sh
 
 hipError_t vt_launch_preprocess_u8(const unsigned char* in_hwc, float* out_nchw, int B, int H, int W, hipStream_t s);
 
-// row softmax: scores fp32 [rows][lds] -> probs bf16 [rows][ldp]; columns [n, ldp) are written as zero.
-hipError_t vt_launch_softmax_rows(const float* scores, bf16_t* probs, int rows, int n, int lds, int ldp,
-                                  hipStream_t s);
+// row softmax: scores fp32 or fp16 [rows][lds] -> probs bf16 [rows][ldp]; columns [n, ldp) are written as zero.
+hipError_t vt_launch_softmax_rows(const void* scores, int scores_f16, bf16_t* probs, long long rows, int n, int lds,
+                                  int ldp, hipStream_t s);
 
 // decoder (all fp32)
 struct DecoderWeights;   // defined in capi.hip
