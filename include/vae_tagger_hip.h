@@ -91,6 +91,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         0 (default) = as a standalone HBM-bound pass (one read + one bf16 write of the tensor).
  * flag 3: 1 (default) = 128-cout 3x3 convs use the 16x16-pixel tile that lets two workgroups share a CU,
  *         0 = the 32x16-pixel one-workgroup-per-CU tile (process-wide).
+ * flag 4: 1 (default) = the residual stream between resnet blocks is STORED as fp16 (all arithmetic stays fp32;
+ *         halves the HBM traffic of the conv2 epilogues and of norm1), 0 = stored as fp32.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

@@ -128,15 +128,15 @@ class Ops:
         torch.cuda.synchronize()
         return out[:, :, :N].float().cpu()
 
-    def groupnorm(self, x_nchw, gamma, beta, groups=32, eps=1e-6, silu=True, in_bf16=False):
+    def groupnorm(self, x_nchw, gamma, beta, groups=32, eps=1e-6, silu=True, in_bf16=False, in_f16=False):
         B, C, H, W = x_nchw.shape
-        x = nhwc(x_nchw).to(self.dev, torch.bfloat16 if in_bf16 else torch.float32)
+        x = nhwc(x_nchw).to(self.dev, torch.bfloat16 if in_bf16 else (torch.float16 if in_f16 else torch.float32))
         y = torch.zeros(B, H, W, C, device=self.dev, dtype=torch.bfloat16)
         n = self.ctx.lib.vt_op_groupnorm_workspace_bytes(B, H * W, C)
         ws = torch.empty(n + 256, device=self.dev, dtype=torch.uint8)
         g = gamma.to(self.dev, torch.float32).contiguous()
         bt = beta.to(self.dev, torch.float32).contiguous()
-        self.ctx.call("vt_op_groupnorm", vp(x), self.L.VT_BF16 if in_bf16 else self.L.VT_F32, B, H * W, C, groups,
+        self.ctx.call("vt_op_groupnorm", vp(x), self.L.VT_BF16 if in_bf16 else (self.L.VT_F16 if in_f16 else self.L.VT_F32), B, H * W, C, groups,
                       float(eps), vp(g), vp(bt), int(silu), vp(y), vp(ws), self.stream)
         torch.cuda.synchronize()
         return nchw(y.float().cpu())

@@ -147,6 +147,16 @@ def test_groupnorm_silu_matches_torch(ops, C, H, W, in_bf16, silu):
     assert torch.allclose(got, ref, rtol=6e-3, atol=2e-3), (got - ref).abs().max()
 
 
+def test_groupnorm_fp16_input(ops):
+    """the residual stream is stored as fp16 by default: GroupNorm reads it directly"""
+    x = (_rand((2, 256, 24, 20), 19) * 1.3 + 0.4).to(torch.float16).to(torch.float32)
+    g = 1 + 0.1 * _rand((256,), 10)
+    b = 0.1 * _rand((256,), 11)
+    ref = F.silu(F.group_norm(x, 32, g, b, eps=1e-6))
+    got = ops.groupnorm(x, g, b, silu=True, in_f16=True)
+    assert torch.allclose(got, ref, rtol=6e-3, atol=2e-3), (got - ref).abs().max()
+
+
 def test_groupnorm_large_mean_is_stable(ops):
     x = _rand((1, 128, 32, 32), 12) * 0.05 + 30.0          # mean >> std: catastrophic for naive E[x^2]-E[x]^2 in fp32
     g, b = torch.ones(128), torch.zeros(128)

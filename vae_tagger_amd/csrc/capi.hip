@@ -79,6 +79,7 @@ struct vt_context {
     int use_halo_conv = 1;          // vt_set_flag(ctx, 0, v)
     int fuse_gn_stats = 1;          // vt_set_flag(ctx, 1, v)
     int fuse_gn_apply = 0;          // vt_set_flag(ctx, 2, v): break-even on MI355X today, off by default
+    int res_fp16 = 1;               // vt_set_flag(ctx, 4, v): residual stream stored as fp16 (math stays fp32)
     void* op_scratch = nullptr; size_t op_scratch_bytes = 0;
 
     // optional per-launch timing of the MFMA kernel (HIP events on the launch stream)
@@ -227,41 +228,46 @@ struct GnState {
 };
 
 // y = act(GroupNorm(x)) as bf16 rows.  Uses epilogue-produced partials when present.
-int run_gn(vt_context* c, const void* x, int is_f32, int B, int HW, const NormW& n, int groups, int silu, bf16_t* y,
+int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int B, int HW, const NormW& n, int groups, int silu, bf16_t* y,
            GnState& g, hipStream_t s) {
     int parts = g.parts;
-    if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, is_f32, B, HW, n.c, groups, g.partial, &parts, s), "gn_stats");
+    if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, xdt, B, HW, n.c, groups, g.partial, &parts, s), "gn_stats");
     g.parts = 0;
     HIPCK(c, vt_launch_gn_finalize(g.partial, parts, B, n.c, groups, 1e-6f, n.g, n.b, g.ss, s), "gn_finalize");
     if (c->profiling) {
         vt_context::ProfRec r;
         r.e0 = c->next_event(); r.e1 = c->next_event();
         if (!r.e0 || !r.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
-        r.flops = (double)B * HW * n.c * (is_f32 ? 6.0 : 4.0);       // algorithmic bytes: one read + one bf16 write
+        r.flops = (double)B * HW * n.c * (xdt == 1 ? 6.0 : 4.0);     // algorithmic bytes: one read + one bf16 write
         r.cfg = VT_PROF_GN_APPLY;
         HIPCK(c, hipEventRecord(r.e0, s), "hipEventRecord");
-        HIPCK(c, vt_launch_gn_apply(x, is_f32, g.ss, y, B, HW, n.c, silu, s), "gn_apply");
+        HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s), "gn_apply");
         HIPCK(c, hipEventRecord(r.e1, s), "hipEventRecord");
         c->prof.push_back(r);
         return VT_OK;
     }
-    HIPCK(c, vt_launch_gn_apply(x, is_f32, g.ss, y, B, HW, n.c, silu, s), "gn_apply");
+    HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s), "gn_apply");
     return VT_OK;
 }
 
 // `gn`: if non-null, the epilogue also writes GroupNorm partials of the output (cpg = cout / groups)
 // `xnorm_f32` / `ss`: when ss is given the conv input is silu(x*scale + shift) with x = xnorm_f32 (fp32) or x (bf16),
 // fused into the halo staging (only valid when norm_conv_fusable()).
+// `res` / `oh` are the residual-stream tensors (input to add, output to write): fp32 when rdt == 1, fp16 when rdt == 2.
 int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int Win, int stride, int pad, int Hout,
-             int Wout, const float* res, float* o32, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32,
-             const float* xnorm_f32 = nullptr, const float* ss = nullptr) {
+             int Wout, const void* res, void* oh, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32,
+             const float* xnorm_f32 = nullptr, const float* ss = nullptr, int rdt = 1) {
+    const float* res32 = rdt == 1 ? (const float*)res : nullptr;
+    const f16_t* res16 = rdt == 2 ? (const f16_t*)res : nullptr;
+    float* o32 = rdt == 1 ? (float*)oh : nullptr;
+    f16_t* oh16 = rdt == 2 ? (f16_t*)oh : nullptr;
     const int cpg = w.cout / groups;
     const bool fuse = gn && c->fuse_gn_stats && (cpg == 4 || cpg == 8 || cpg == 16);
     if (gn) gn->parts = 0;
     if (c->use_halo_conv && w.wp && w.k == 3 && stride == 1 && pad == 1 && Hout == Hin && Wout == Win) {
         Conv3x3Args h{};
         h.X = xnorm_f32 ? nullptr : x; h.Xf32 = xnorm_f32; h.scale_shift = ss;
-        h.Wp = w.wp; h.bias = w.b; h.res = res; h.out_f32 = o32; h.out_bf16 = o16; h.zeros = c->zeros;
+        h.Wp = w.wp; h.bias = w.b; h.res = res32; h.res_f16 = res16; h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout, ss != nullptr); }
         HIPCK(c, launch_halo(c, h, s), "conv3x3_halo");
@@ -269,7 +275,7 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     }
     if (ss) return c->fail(VT_ERR_STATE, "internal: fused norm requested for a conv the halo kernel cannot run");
     ConvGemmArgs a{};
-    a.X = x; a.W = w.w; a.bias = w.b; a.res = res; a.out_f32 = o32; a.out_bf16 = o16; a.zeros = c->zeros;
+    a.X = x; a.W = w.w; a.bias = w.b; a.res = res32; a.res_f16 = res16; a.out_f32 = o32; a.out_f16 = oh16; a.out_bf16 = o16; a.zeros = c->zeros;
     a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cin = w.cin; a.Cout = w.cout; a.Wrows = w.cout;
     a.ksize = w.k; a.stride = stride; a.pad = pad;
     a.ldx = w.cin; a.ldw = w.k * w.k * w.cin; a.ldo = w.cout; a.ldr = w.cout;
@@ -289,21 +295,21 @@ bool norm_conv_fusable(const vt_context* c, const ConvW& w, int cin) {
 // conv3x3(silu(GroupNorm(x))) with x fp32 (x32) or bf16 (x16).  Statistics come from the producer's epilogue
 // when available (gn.parts > 0); the normalise+SiLU runs inside the conv's halo staging when the halo kernel
 // applies, otherwise as the standalone pass into `act`.
-int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const float* x32, const bf16_t* x16, int B, int H, int W,
-                  int groups, bf16_t* act, const float* res, float* o32, bf16_t* o16, GnState& gn, bool want_stats,
-                  hipStream_t s) {
-    const void* x = x32 ? (const void*)x32 : (const void*)x16;
-    const int is_f32 = x32 != nullptr;
-    if (!norm_conv_fusable(c, w, n.c)) {
-        int r = run_gn(c, x, is_f32, B, H * W, n, groups, 1, act, gn, s);
+// x: the tensor to normalise (xdt 0 = bf16 conv output, 1 = fp32 / 2 = fp16 residual stream); res / oh: residual in / out (rdt).
+int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, int xdt, int B, int H, int W,
+                  int groups, bf16_t* act, const void* res, void* oh, bf16_t* o16, GnState& gn, bool want_stats,
+                  hipStream_t s, int rdt) {
+    if (xdt == 2 || !norm_conv_fusable(c, w, n.c)) {          // (the fused staging reads fp32 or bf16 only)
+        int r = run_gn(c, x, xdt, B, H * W, n, groups, 1, act, gn, s);
         if (r) return r;
-        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, o32, o16, s, want_stats ? &gn : nullptr, groups);
+        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt);
     }
     int parts = gn.parts;
-    if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, is_f32, B, H * W, n.c, groups, gn.partial, &parts, s), "gn_stats");
+    if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, xdt, B, H * W, n.c, groups, gn.partial, &parts, s), "gn_stats");
     gn.parts = 0;
     HIPCK(c, vt_launch_gn_finalize(gn.partial, parts, B, n.c, groups, 1e-6f, n.g, n.b, gn.ss, s), "gn_finalize");
-    return run_conv(c, w, x16, B, H, W, 1, 1, H, W, res, o32, o16, s, want_stats ? &gn : nullptr, groups, x32, gn.ss);
+    return run_conv(c, w, xdt == 0 ? (const bf16_t*)x : nullptr, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr,
+                    groups, xdt == 1 ? (const float*)x : nullptr, gn.ss, rdt);
 }
 
 struct AttnScratch { bf16_t* qk; bf16_t* vt; f16_t* scores; bf16_t* probs; bf16_t* o; int group; };
@@ -337,8 +343,8 @@ AttnScratch carve_attn(char* p, int B, int S, int C) {
 
 // diffusers Attention for the VAE mid block: 1 head, dim_head = C, scale 1/sqrt(C).
 // x16: group-normed tokens [B][S][C] bf16.  out = to_out(softmax(q k^T / sqrt(C)) v) + residual.
-int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const float* res, float* out32, int B, int S,
-                  const AttnScratch& sc, hipStream_t s, GnState* gn = nullptr, int groups = 32) {
+int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* res, void* out, int B, int S,
+                  const AttnScratch& sc, hipStream_t s, GnState* gn = nullptr, int groups = 32, int rdt = 1) {
     const int C = w.c;
     const int ld = (S + 7) / 8 * 8;
     ConvGemmArgs a{};
@@ -369,7 +375,8 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const float*
         HIPCK(c, launch_gemm(c, a, s), "attn pv");
     }
     // out = o Wo^T + bo + residual -> fp32 [B][S][C]
-    a.X = sc.o; a.W = w.wo; a.bias = w.bo; a.bias_mode = 1; a.res = res; a.out_f32 = out32; a.out_bf16 = nullptr;
+    a.X = sc.o; a.W = w.wo; a.bias = w.bo; a.bias_mode = 1; a.out_bf16 = nullptr;
+    if (rdt == 1) { a.res = (const float*)res; a.out_f32 = (float*)out; } else { a.res_f16 = (const f16_t*)res; a.out_f16 = (f16_t*)out; }
     a.Win = a.Wout = S; a.Cin = C; a.Cout = C; a.Wrows = C; a.ldx = C; a.ldw = C; a.ldo = C; a.ldr = C;
     a.x_bs = (long long)S * C; a.w_bs = 0; a.o_bs = a.x_bs; a.r_bs = a.x_bs; a.batch = B; a.alpha = 1.f;
     if (gn) {
@@ -592,8 +599,10 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
     hipStream_t s = (hipStream_t)stream;
     const size_t slack = 4096;
     char* q = (char*)ws;
-    float* f32[3]; bf16_t* b16[3];
-    for (int i = 0; i < 3; ++i) { f32[i] = (float*)q; q += align_up(p.max_elems * B * 4 + slack); }
+    // residual-stream buffers: fp16 by default (res_fp16), fp32 otherwise; sized for fp32 either way
+    const int rdt = c->res_fp16 ? 2 : 1;
+    void* f32[3]; bf16_t* b16[3];
+    for (int i = 0; i < 3; ++i) { f32[i] = (void*)q; q += align_up(p.max_elems * B * 4 + slack); }
     for (int i = 0; i < 3; ++i) { b16[i] = (bf16_t*)q; q += align_up(p.max_elems * B * 2 + slack); }
     GnState gn;
     gn.partial = (float*)q; q += align_up((size_t)B * p.max_chunks * e.groups * 3 * 4);
@@ -611,7 +620,8 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
         const int cpg0 = e.block_out[0] / e.groups;
         const bool fuse0 = c->fuse_gn_stats && (cpg0 % 4) == 0;
         int parts = 0;
-        HIPCK(c, vt_launch_conv_in(x, e.conv_in_w, e.conv_in_b, f32[cur], nullptr, fuse0 ? gn.partial : nullptr, cpg0, &parts,
+        HIPCK(c, vt_launch_conv_in(x, e.conv_in_w, e.conv_in_b, rdt == 1 ? (float*)f32[cur] : nullptr, nullptr,
+                                   rdt == 2 ? (f16_t*)f32[cur] : nullptr, fuse0 ? gn.partial : nullptr, cpg0, &parts,
                                    B, H, W, e.block_out[0], s), "conv_in");
         gn.parts = fuse0 ? parts : 0;
     }
@@ -619,18 +629,18 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
     // one ResnetBlock2D: h <- conv2(silu(gn(conv1(silu(gn(h)))))) + shortcut(h)
     auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out) -> int {
         const int nxt = (cur + 1) % 3, scb = (cur + 2) % 3;
-        const float* res = f32[cur];
+        const void* res = f32[cur];
         int rr;
         if (rw.has_sc) {
-            if ((rr = run_conv(c, rw.sc, h16_for_shortcut, B, h, w, 1, 0, h, w, nullptr, f32[scb], nullptr, s))) return rr;
+            if ((rr = run_conv(c, rw.sc, h16_for_shortcut, B, h, w, 1, 0, h, w, nullptr, f32[scb], nullptr, s, nullptr, 32, nullptr, nullptr, rdt))) return rr;
             res = f32[scb];
         }
-        if ((rr = run_norm_conv(c, rw.n1, rw.c1, f32[cur], nullptr, B, h, w, e.groups, act, nullptr, nullptr, tmid, gn, true, s))) return rr;
+        if ((rr = run_norm_conv(c, rw.n1, rw.c1, f32[cur], rdt, B, h, w, e.groups, act, nullptr, nullptr, tmid, gn, true, s, rdt))) return rr;
         if (want_bf16_out) {
             // the only consumer is the downsample conv (bf16 operand, no norm): skip the fp32 copy of h and the stats
-            return run_norm_conv(c, rw.n2, rw.c2, nullptr, tmid, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s);
+            return run_norm_conv(c, rw.n2, rw.c2, tmid, 0, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt);
         }
-        if ((rr = run_norm_conv(c, rw.n2, rw.c2, nullptr, tmid, B, h, w, e.groups, act, res, f32[nxt], nullptr, gn, true, s))) return rr;
+        if ((rr = run_norm_conv(c, rw.n2, rw.c2, tmid, 0, B, h, w, e.groups, act, res, f32[nxt], nullptr, gn, true, s, rdt))) return rr;
         cur = nxt;
         return VT_OK;
     };
@@ -649,7 +659,7 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             const int ho = h / 2, wo = w / 2;
             const int nxt = (cur + 1) % 3;
             const bool next_has_sc = (i + 1 < e.stages.size()) && e.stages[i + 1].res[0].has_sc;
-            if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], next_has_sc ? tmid : nullptr, s, &gn, e.groups))) return r;
+            if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], next_has_sc ? tmid : nullptr, s, &gn, e.groups, nullptr, nullptr, rdt))) return r;
             // the bf16 copy lives in tmid until the next resnet's conv1 overwrites it; the shortcut conv runs first
             h16 = next_has_sc ? tmid : nullptr;
             cur = nxt; h = ho; w = wo;
@@ -658,12 +668,12 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
     if ((r = resnet(e.mid0, nullptr, false))) return r;
     {
         const int S = h * w, nxt = (cur + 1) % 3;
-        if ((r = run_gn(c, f32[cur], 1, B, S, e.attn.gn, e.groups, 0, act, gn, s))) return r;
-        if ((r = run_attention(c, e.attn, act, f32[cur], f32[nxt], B, S, as, s, &gn, e.groups))) return r;
+        if ((r = run_gn(c, f32[cur], rdt, B, S, e.attn.gn, e.groups, 0, act, gn, s))) return r;
+        if ((r = run_attention(c, e.attn, act, f32[cur], f32[nxt], B, S, as, s, &gn, e.groups, rdt))) return r;
         cur = nxt;
     }
     if ((r = resnet(e.mid1, nullptr, false))) return r;
-    if ((r = run_gn(c, f32[cur], 1, B, h * w, e.norm_out, e.groups, 1, act, gn, s))) return r;
+    if ((r = run_gn(c, f32[cur], rdt, B, h * w, e.norm_out, e.groups, 1, act, gn, s))) return r;
     {
         // conv_out -> moments; mode() = mean = first `latent` channels; optional * scaling + shift
         ConvGemmArgs a{};
@@ -836,6 +846,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 1) { c->fuse_gn_stats = value != 0; return VT_OK; }
     if (flag == 2) { c->fuse_gn_apply = value != 0; return VT_OK; }
     if (flag == 3) { vt_conv3x3_halo_set_occ2(value); return VT_OK; }       // process-wide: halo kernel geometry
+    if (flag == 4) { c->res_fp16 = value != 0; return VT_OK; }
     return c->fail(VT_ERR_INVALID, "vt_set_flag: unknown flag %d", flag);
 }
 
@@ -993,7 +1004,7 @@ int vt_op_conv_in(vt_context* c, const float* x, const float* w_oihw, const floa
     HIPCK(c, hipMemcpy(hw.data(), w_oihw, hw.size() * 4, hipMemcpyDeviceToHost), "vt_op_conv_in copy");
     for (int o = 0; o < Cout; ++o) for (int k = 0; k < 27; ++k) pk[(size_t)k * Cout + o] = hw[(size_t)o * 27 + k];
     HIPCK(c, hipMemcpy(ws, pk.data(), pk.size() * 4, hipMemcpyHostToDevice), "vt_op_conv_in copy");
-    HIPCK(c, vt_launch_conv_in(x, (const float*)ws, bias, o32, (bf16_t*)o16, nullptr, 0, nullptr, B, H, W, Cout, (hipStream_t)stream), "vt_op_conv_in");
+    HIPCK(c, vt_launch_conv_in(x, (const float*)ws, bias, o32, (bf16_t*)o16, nullptr, nullptr, 0, nullptr, B, H, W, Cout, (hipStream_t)stream), "vt_op_conv_in");
     return VT_OK;
 }
 
@@ -1006,13 +1017,13 @@ int vt_op_groupnorm(vt_context* c, const void* x, int x_dtype, int B, int HW, in
                     const float* gamma, const float* beta, int silu, void* y, void* ws, void* stream) {
     if (!c) return VT_ERR_INVALID;
     if (!x || !gamma || !beta || !y || !ws) return c->fail(VT_ERR_INVALID, "vt_op_groupnorm: null buffer");
-    if (x_dtype != VT_F32 && x_dtype != VT_BF16) return c->fail(VT_ERR_INVALID, "vt_op_groupnorm: dtype must be f32 or bf16");
+    if (x_dtype != VT_F32 && x_dtype != VT_BF16 && x_dtype != VT_F16) return c->fail(VT_ERR_INVALID, "vt_op_groupnorm: dtype must be f32, bf16 or f16");
     if (groups > 64) return c->fail(VT_ERR_INVALID, "vt_op_groupnorm: groups > 64");
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)ws;
     float* ss = (float*)((char*)ws + align_up((size_t)B * vt_gn_max_chunks(HW, C) * 64 * 3 * 4));
     int nchunks = 0;
-    const int f = x_dtype == VT_F32;
+    const int f = x_dtype == VT_F32 ? 1 : (x_dtype == VT_F16 ? 2 : 0);
     HIPCK(c, vt_launch_gn_stats(x, f, B, HW, C, groups, partial, &nchunks, s), "gn_stats");
     HIPCK(c, vt_launch_gn_finalize(partial, nchunks, B, C, groups, eps, gamma, beta, ss, s), "gn_finalize");
     HIPCK(c, vt_launch_gn_apply(x, f, ss, (bf16_t*)y, B, HW, C, silu, s), "gn_apply");

@@ -429,6 +429,26 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             if (a.out_f32) *(f32x4*)(a.out_f32 + o + 4 * i) = v;
             acc[i][j] = v;
         }
+        if (a.res_f16) {
+            // fp16 residual stream: the lane's 16 couts are 32 contiguous bytes
+#pragma unroll
+            for (int i = 0; i < TC; i += 2) {
+                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                const f16x8 rh = *(const f16x8*)(a.res_f16 + o + 4 * i);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[i][j][r] += (float)rh[r]; acc[i + 1][j][r] += (float)rh[4 + r]; }
+            }
+        }
+        if (a.out_f16) {
+#pragma unroll
+            for (int i = 0; i < TC; i += 2) {
+                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                f16x8 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { h[r] = (f16_t)acc[i][j][r]; h[4 + r] = (f16_t)acc[i + 1][j][r]; }
+                *(f16x8*)(a.out_f16 + o + 4 * i) = h;
+            }
+        }
         if (a.out_bf16) {
 #pragma unroll
             for (int i = 0; i < TC; i += 2) {
@@ -509,7 +529,8 @@ int vt_conv3x3_halo_config(const Conv3x3Args& a) {      // profile slots 3..8 = 
 }
 
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
-    if (!a.Wp || !a.zeros || (!a.out_f32 && !a.out_bf16)) return hipErrorInvalidValue;
+    if (!a.Wp || !a.zeros || (!a.out_f32 && !a.out_bf16 && !a.out_f16)) return hipErrorInvalidValue;
+    if ((a.res && a.res_f16) || (a.res_f16 && a.out_f32)) return hipErrorInvalidValue;
     if (!vt_conv3x3_halo_supported(a.Cin, a.Cout) || a.batch <= 0 || a.H <= 0 || a.W <= 0) return hipErrorInvalidValue;
     if (a.gn_partial && a.gn_cpg != 4 && a.gn_cpg != 8 && a.gn_cpg != 16) return hipErrorInvalidValue;
     if ((long long)a.H * a.W * a.Cin >= (1LL << 31)) return hipErrorInvalidValue;        // 32-bit per-image offsets

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const ConvGemmArgs a) {
     // ---- epilogue: lane holds couts cg..cg+3 (regs) of pixel p for every (i, j) tile.
     const long long ob = (long long)b * a.o_bs;
     const float* resb = a.res ? a.res + (long long)b * a.r_bs : nullptr;
+    const f16_t* resh = a.res_f16 ? a.res_f16 + (long long)b * a.r_bs : nullptr;
     unsigned valid = 0;
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
@@ -199,6 +200,9 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const ConvGemmArgs a) {
             if (resb) {
                 const f32x4 rv = *(const f32x4*)(resb + (long long)p * a.ldr + cg);
                 v += rv;
+            } else if (resh) {
+                const f16x4 rh = *(const f16x4*)(resh + (long long)p * a.ldr + cg);
+                v += f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
             }
             if (a.out_f32) *(f32x4*)(a.out_f32 + ob + o) = v;
             if (a.out_bf16) {
@@ -250,7 +254,8 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
     if (a.Cin <= 0 || a.Cout <= 0 || a.batch <= 0 || a.Wrows <= 0 || a.Wrows > a.Cout) return hipErrorInvalidValue;
     if ((a.ldx % 8) || (a.ldw % 8)) return hipErrorInvalidValue;          // 16-B aligned rows for the DMA
     if (a.out_mode == 0 && ((a.ldo % 4) || (a.Cout % 4))) return hipErrorInvalidValue;
-    if (a.res && (a.ldr % 4)) return hipErrorInvalidValue;
+    if ((a.res || a.res_f16) && (a.ldr % 4)) return hipErrorInvalidValue;
+    if (a.res && a.res_f16) return hipErrorInvalidValue;
     if (a.Cin % 8) return hipErrorInvalidValue;                           // k tail handled per 8-element chunk
     if (a.gn_partial) {
         if (a.gn_cpg != 4 && a.gn_cpg != 8 && a.gn_cpg != 16) return hipErrorInvalidValue;

@@ -20,6 +20,14 @@ template <> struct Load8<float> {
         v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     }
 };
+template <> struct Load8<f16_t> {
+    static __device__ __forceinline__ void ld(const f16_t* p, float (&v)[8]) {
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        const f16x8 a = *(const f16x8*)p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
+};
 template <> struct Load8<bf16_t> {
     static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
         const bf16x8 a = *(const bf16x8*)p;
@@ -197,7 +205,7 @@ int vt_gn_max_chunks(int HW, int C) {
     return (HW + cp - 1) / cp;
 }
 
-hipError_t vt_launch_gn_stats(const void* x, int x_is_f32, int B, int HW, int C, int groups, float* partial,
+hipError_t vt_launch_gn_stats(const void* x, int x_dtype, int B, int HW, int C, int groups, float* partial,
                               int* nchunks_out, hipStream_t s) {
     if (!gn_shape_ok(C, groups) || B <= 0 || HW <= 0) return hipErrorInvalidValue;
     const int cpg = C / groups;
@@ -207,8 +215,10 @@ hipError_t vt_launch_gn_stats(const void* x, int x_is_f32, int B, int HW, int C,
     dim3 grid(nchunks, B), block(GN_THREADS);
     const int slots = cpg >= 8 ? 1 : 8 / cpg;
 #define GN_STATS(T, S) hipLaunchKernelGGL((gn_stats_kernel<T, S>), grid, block, 0, s, (const T*)x, HW, C, cpg, cp, nchunks, partial)
-    if (x_is_f32) {
+    if (x_dtype == 1) {
         if (slots == 1) GN_STATS(float, 1); else if (slots == 2) GN_STATS(float, 2); else GN_STATS(float, 4);
+    } else if (x_dtype == 2) {
+        if (slots == 1) GN_STATS(f16_t, 1); else if (slots == 2) GN_STATS(f16_t, 2); else GN_STATS(f16_t, 4);
     } else {
         if (slots == 1) GN_STATS(bf16_t, 1); else if (slots == 2) GN_STATS(bf16_t, 2); else GN_STATS(bf16_t, 4);
     }
@@ -224,7 +234,7 @@ hipError_t vt_launch_gn_finalize(const float* partial, int nparts, int B, int C,
     return hipGetLastError();
 }
 
-hipError_t vt_launch_gn_apply(const void* x, int x_is_f32, const float* scale_shift, bf16_t* y, int B, int HW,
+hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shift, bf16_t* y, int B, int HW,
                               int C, int silu, hipStream_t s) {
     if (C % 8 || (GN_THREADS % (C / 8)) != 0 || C / 8 > GN_THREADS || B <= 0 || HW <= 0) return hipErrorInvalidValue;
     const int ppp = GN_THREADS / (C / 8);
@@ -232,7 +242,8 @@ hipError_t vt_launch_gn_apply(const void* x, int x_is_f32, const float* scale_sh
     if (ppb < ppp) ppb = ppp;
     dim3 grid((HW + ppb - 1) / ppb, B), block(GN_THREADS);
 #define GN_APPLY(T, A) hipLaunchKernelGGL((gn_apply_kernel<T, A>), grid, block, 0, s, (const T*)x, scale_shift, y, HW, C, ppb)
-    if (x_is_f32) { if (silu) GN_APPLY(float, true); else GN_APPLY(float, false); }
+    if (x_dtype == 1) { if (silu) GN_APPLY(float, true); else GN_APPLY(float, false); }
+    else if (x_dtype == 2) { if (silu) GN_APPLY(f16_t, true); else GN_APPLY(f16_t, false); }
     else { if (silu) GN_APPLY(bf16_t, true); else GN_APPLY(bf16_t, false); }
 #undef GN_APPLY
     return hipGetLastError();

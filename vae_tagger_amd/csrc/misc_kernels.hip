@@ -15,7 +15,8 @@ namespace {
 constexpr int CI_PIX = 64, CI_ROWS = 16;
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                       const float* __restrict__ bias, float* __restrict__ o32,
-                                                      bf16_t* __restrict__ o16, float* __restrict__ gn_partial,
+                                                      bf16_t* __restrict__ o16, f16_t* __restrict__ oh,
+                                                      float* __restrict__ gn_partial,
                                                       int gn_cpg, int H, int W, int Cout) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int RW = CI_PIX + 2, RH = CI_ROWS + 2;
@@ -83,6 +84,13 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 #pragma unroll
                     for (int i = 0; i < 8; ++i) h[i] = (bf16_t)acc[p][i];
                     *(bf16x8*)(o16 + o) = h;
+                }
+                if (oh) {
+                    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                    f16x8 h;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) h[i] = (f16_t)acc[p][i];
+                    *(f16x8*)(oh + o) = h;
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -225,16 +233,16 @@ hipError_t vt_launch_preprocess_u8(const unsigned char* in_hwc, float* out_nchw,
     return hipGetLastError();
 }
 
-hipError_t vt_launch_conv_in(const float* x, const float* wp, const float* bias, float* o32, bf16_t* o16,
+hipError_t vt_launch_conv_in(const float* x, const float* wp, const float* bias, float* o32, bf16_t* o16, f16_t* oh,
                              float* gn_partial, int gn_cpg, int* gn_parts, int B, int H, int W, int Cout, hipStream_t s) {
-    if (!x || !wp || !bias || (!o32 && !o16) || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 8))
+    if (!x || !wp || !bias || (!o32 && !o16 && !oh) || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 8))
         return hipErrorInvalidValue;
     if (gn_partial && ((gn_cpg % 4) || gn_cpg <= 0 || (Cout % gn_cpg) || Cout / gn_cpg > 256)) return hipErrorInvalidValue;
     const size_t smem = (size_t)(27 * Cout + 3 * (CI_ROWS + 2) * (CI_PIX + 2) + (Cout / 4) * 16 * 3) * sizeof(float);
     if (smem > 64 * 1024) return hipErrorInvalidValue;
     dim3 grid((W + CI_PIX - 1) / CI_PIX, (H + CI_ROWS - 1) / CI_ROWS, B);
     if (gn_parts) *gn_parts = grid.x * grid.y;
-    hipLaunchKernelGGL(conv_in_kernel, grid, dim3(256), smem, s, x, wp, bias, o32, o16, gn_partial, gn_cpg, H, W, Cout);
+    hipLaunchKernelGGL(conv_in_kernel, grid, dim3(256), smem, s, x, wp, bias, o32, o16, oh, gn_partial, gn_cpg, H, W, Cout);
     return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@ struct ConvGemmArgs {
     const bf16_t* W;        // [Cout][taps][Cin] bf16 (k contiguous) / generic row-major B^T operand
     const float* bias;      // fp32, per cout (mode 1) or per pixel-row (mode 2)
     const float* res;       // optional fp32 residual, indexed like the output rows
+    const f16_t* res_f16;   // ... or fp16 residual (at most one of res / res_f16)
     float* out_f32;         // optional fp32 output rows [p][ldo]
     bf16_t* out_bf16;       // optional bf16 output rows [p][ldo]
     f16_t* out_f16;         // optional fp16 output rows [p][ldo] (attention scores)
@@ -44,8 +45,10 @@ struct Conv3x3Args {
     const bf16_t* Wp;       // packed [Cin/32][9][Cout][32] bf16
     const float* bias;      // [Cout] or null
     const float* res;       // optional fp32 residual [batch][H][W][Cout]
+    const f16_t* res_f16;   // ... or fp16 residual (at most one of res / res_f16)
     float* out_f32;         // optional
     bf16_t* out_bf16;       // optional
+    f16_t* out_f16;         // optional (fp16 residual stream)
     const void* zeros;
     float* gn_partial;      // optional [batch][tiles][Cout/gn_cpg][3] (n, mean, M2) of the output values
     int gn_cpg;             // channels per GroupNorm group of the OUTPUT (4, 8 or 16)
@@ -63,20 +66,21 @@ hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w_ohwi, bf16_t* wp, int C
 // conv_in: fp32 NCHW image -> NHWC 128-channel fp32 (+ optional bf16) rows, direct fp32 conv 3x3 p1.
 // gn_partial (optional): (n, mean, M2) triples of the output, [B][parts][Cout/gn_cpg][3]; *gn_parts receives `parts`.
 hipError_t vt_launch_conv_in(const float* x_nchw, const float* w_packed /*[27][Cout]*/, const float* bias,
-                             float* out_f32, bf16_t* out_bf16, float* gn_partial, int gn_cpg, int* gn_parts, int B, int H,
-                             int W, int Cout, hipStream_t s);
+                             float* out_f32, bf16_t* out_bf16, f16_t* out_f16, float* gn_partial, int gn_cpg, int* gn_parts,
+                             int B, int H, int W, int Cout, hipStream_t s);
 int vt_conv_in_parts(int H, int W);
 
-// GroupNorm statistics: x rows [B][HW][C] (fp32 or bf16) -> partial (count, mean, M2) per
+// x_dtype below: 0 = bf16, 1 = fp32, 2 = fp16.
+// GroupNorm statistics: x rows [B][HW][C] -> partial (count, mean, M2) per
 // (b, chunk, group), then finalize -> per (b, c) scale/shift so that y = x*scale + shift.
-hipError_t vt_launch_gn_stats(const void* x, int x_is_f32, int B, int HW, int C, int groups,
+hipError_t vt_launch_gn_stats(const void* x, int x_dtype, int B, int HW, int C, int groups,
                               float* partial, int* nchunks_out, hipStream_t s);
 hipError_t vt_launch_gn_finalize(const float* partial /*[B][nparts][groups][3]*/, int nparts, int B, int C, int groups,
                                  float eps, const float* gamma, const float* beta, float* scale_shift /*[B][C][2]*/,
                                  hipStream_t s);
 int vt_gn_max_chunks(int HW, int C);
 // y = act(x*scale + shift) -> bf16 rows
-hipError_t vt_launch_gn_apply(const void* x, int x_is_f32, const float* scale_shift, bf16_t* y, int B, int HW,
+hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shift, bf16_t* y, int B, int HW,
                               int C, int silu, hipStream_t s);
 
 hipError_t vt_launch_preprocess_u8(const unsigned char* in_hwc, float* out_nchw, int B, int H, int W, hipStream_t s);
