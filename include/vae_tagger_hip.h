@@ -93,6 +93,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         0 = the 32x16-pixel one-workgroup-per-CU tile (process-wide).
  * flag 4: 1 (default) = the residual stream between resnet blocks is STORED as fp16 (all arithmetic stays fp32;
  *         halves the HBM traffic of the conv2 epilogues and of norm1), 0 = stored as fp32.
+ * flag 5: 1 (default) = conv_in (3 -> 128 channels) runs on the matrix cores from a bf16 im2col operand,
+ *         0 = exact fp32 VALU conv.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

@@ -1,0 +1,45 @@
+"""Determinism check of the halo conv through the op-level C ABI: the same launch repeated N times must give
+bit-identical outputs and GroupNorm partials.  Usage: python tools/race_check.py [lib.so] [reps]"""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vae_tagger_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1] != "-":
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+ctx = _lib.Context(0); dev = torch.device("cuda:0")
+vp = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+print("lib:", _lib.LIB_PATH, flush=True)
+for (B, H, W, Cin, Cout) in ((2, 1024, 1024, 128, 128), (2, 512, 512, 256, 256), (4, 256, 256, 512, 512)):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * (Cin * 9) ** -0.5).to(dev, torch.bfloat16)
+    b = torch.randn(Cout, generator=g).to(dev); gam = torch.ones(Cout, device=dev); bet = torch.zeros(Cout, device=dev)
+    o32 = torch.empty(B, H, W, Cout, device=dev)
+    n = ctx.lib.vt_op_conv2d_gn_workspace_bytes(B, H, W, Cout)
+    ws = torch.zeros(n // 4 + 64, device=dev)
+    ss = torch.zeros(B, Cout, 2, device=dev)
+    for occ2 in ((1, 0) if Cout == 128 else (1,)):
+        ctx.call("vt_set_flag", 3, occ2)
+        def run():
+            ctx.call("vt_op_conv2d_gn", vp(x), vp(w), vp(b), None, vp(o32), None, B, H, W, Cin, Cout, 3, 1, 1, 1, 32, 1e-6,
+                     vp(gam), vp(bet), vp(ss), vp(ws), None)
+        run(); torch.cuda.synchronize()
+        ref_o, ref_ss = o32.clone(), ss.clone()
+        bad = 0; badpix = 0
+        for rep in range(reps):
+            run()
+            d = (o32 != ref_o)
+            if d.any().item() or not torch.equal(ss, ref_ss):
+                bad += 1
+                nz = d.nonzero()
+                badpix += nz.shape[0]
+                if bad <= 3 and nz.shape[0]:
+                    ch = sorted(set(nz[:, 3].tolist()))
+                    print(f"   rep {rep}: {nz.shape[0]} elems differ; img {sorted(set(nz[:,0].tolist()))} rows {nz[:,1].min().item()}..{nz[:,1].max().item()} "
+                          f"cols {nz[:,2].min().item()}..{nz[:,2].max().item()} couts {ch[:40]} max|d| {(o32 - ref_o).abs().max().item():.3e}", flush=True)
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(20): run()
+        torch.cuda.synchronize(); ms = (time.time() - t0) / 20 * 1e3
+        print(f"B{B} {H}x{W} {Cin}->{Cout} occ2={occ2}: {bad}/{reps} reps differ ({badpix} elems)  {ms:.3f} ms/op", flush=True)
+ctx.call("vt_set_flag", 3, 1)

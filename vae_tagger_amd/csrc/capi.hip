@@ -34,6 +34,7 @@ struct EncoderW {
     std::vector<int> block_out;
     float scaling = 1.f, shift = 0.f;
     bool has_scaling = false, has_shift = false;
+    const bf16_t* conv_in_wpk = nullptr; // MFMA variant (C0 == 128, 32 groups): [128 rows][32 k] bf16, interleaved cout rows
     const float* conv_in_w = nullptr;   // [27][C0] fp32
     const float* conv_in_b = nullptr;
     std::vector<StageW> stages;
@@ -80,6 +81,7 @@ struct vt_context {
     int fuse_gn_stats = 1;          // vt_set_flag(ctx, 1, v)
     int fuse_gn_apply = 0;          // vt_set_flag(ctx, 2, v): break-even on MI355X today, off by default
     int res_fp16 = 1;               // vt_set_flag(ctx, 4, v): residual stream stored as fp16 (math stays fp32)
+    int conv_in_mfma = 1;           // vt_set_flag(ctx, 5, v): conv_in on the matrix cores (bf16 im2col), else exact fp32 VALU
     void* op_scratch = nullptr; size_t op_scratch_bytes = 0;
 
     // optional per-launch timing of the MFMA kernel (HIP events on the launch stream)
@@ -409,6 +411,8 @@ EncPlan plan_encoder(const EncoderW& e, int B, int H, int W) {
         int ck = vt_gn_max_chunks(hh * ww, ch);
         const int t1 = vt_conv_gemm_ptiles(hh * ww, ch), t2 = vt_conv3x3_halo_tiles(hh, ww, ch, 0), t3 = vt_conv_in_parts(hh, ww);
         if (t3 > ck) ck = t3;
+        const int t4 = vt_conv_in_mfma_parts(hh, ww);
+        if (t4 > ck) ck = t4;
         if (t1 > ck) ck = t1;
         if (t2 > ck) ck = t2;
         if (ck > p.max_chunks) p.max_chunks = ck;
@@ -512,6 +516,15 @@ int vt_encoder_finalize(vt_context* c) {
         e.conv_in_w = (const float*)c->upload(p.data(), p.size() * 4);
         e.conv_in_b = (const float*)c->upload(b->v.data(), b->v.size() * 4);
         if (!e.conv_in_w || !e.conv_in_b) return c->fail(VT_ERR_HIP, "upload failed for conv_in");
+        if (c0 == 128 && e.groups == 32) {
+            std::vector<uint16_t> pk((size_t)128 * 32, 0);
+            for (int o = 0; o < 128; ++o) {
+                const int row = (o & ~63) + vt_halo_row_of_cout(o & 63);
+                for (int k = 0; k < 27; ++k) pk[(size_t)row * 32 + k] = f2bf(w->v[(size_t)o * 27 + k]);
+            }
+            e.conv_in_wpk = (const bf16_t*)c->upload(pk.data(), pk.size() * 2);
+            if (!e.conv_in_wpk) return c->fail(VT_ERR_HIP, "upload failed for conv_in");
+        }
     }
     e.stages.clear();
     int ci = c0;
@@ -620,9 +633,15 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
         const int cpg0 = e.block_out[0] / e.groups;
         const bool fuse0 = c->fuse_gn_stats && (cpg0 % 4) == 0;
         int parts = 0;
-        HIPCK(c, vt_launch_conv_in(x, e.conv_in_w, e.conv_in_b, rdt == 1 ? (float*)f32[cur] : nullptr, nullptr,
-                                   rdt == 2 ? (f16_t*)f32[cur] : nullptr, fuse0 ? gn.partial : nullptr, cpg0, &parts,
-                                   B, H, W, e.block_out[0], s), "conv_in");
+        float* o32 = rdt == 1 ? (float*)f32[cur] : nullptr;
+        f16_t* oh = rdt == 2 ? (f16_t*)f32[cur] : nullptr;
+        if (c->conv_in_mfma && e.conv_in_wpk) {
+            HIPCK(c, vt_launch_conv_in_mfma(x, e.conv_in_wpk, e.conv_in_b, o32, nullptr, oh, fuse0 ? gn.partial : nullptr, &parts,
+                                            B, H, W, s), "conv_in_mfma");
+        } else {
+            HIPCK(c, vt_launch_conv_in(x, e.conv_in_w, e.conv_in_b, o32, nullptr, oh, fuse0 ? gn.partial : nullptr, cpg0, &parts,
+                                       B, H, W, e.block_out[0], s), "conv_in");
+        }
         gn.parts = fuse0 ? parts : 0;
     }
 
@@ -847,6 +866,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 2) { c->fuse_gn_apply = value != 0; return VT_OK; }
     if (flag == 3) { vt_conv3x3_halo_set_occ2(value); return VT_OK; }       // process-wide: halo kernel geometry
     if (flag == 4) { c->res_fp16 = value != 0; return VT_OK; }
+    if (flag == 5) { c->conv_in_mfma = value != 0; return VT_OK; }
     return c->fail(VT_ERR_INVALID, "vt_set_flag: unknown flag %d", flag);
 }
 

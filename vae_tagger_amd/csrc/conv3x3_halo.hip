@@ -254,11 +254,14 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     // SPF (software-pipelined fragments, XT == 0): the MFMA operands of step t+1 are read from LDS DURING step t
     // (each X fragment is refilled as soon as its last MFMA has issued; the W fragments, live until the last MFMA,
     // are refilled at the end of the step and fly during the barrier wait), so after a barrier the matrix pipe
-    // starts at once instead of waiting for 12 ds_read_b128.  That needs W(t+1) landed at the barrier of step t:
-    // the ring is filled one step further ahead (W(t+NW) is issued at step t into the stage whose fragments were
-    // read during step t-1).
+    // starts at once instead of waiting for 12 ds_read_b128.  That needs W(t+1) landed at the barrier of step t.
     constexpr bool SPF = XT == 0;
-    constexpr int LEAD = SPF ? NW : NW - 1;      // W(t + LEAD) is issued at step t
+    // W(t + LEAD) is issued during step t into the stage of W(t-1), whose fragments were read during step t-2: TWO
+    // barriers lie between a stage's last ds_read and the DMA that overwrites it.  (With one barrier -- LEAD = NW --
+    // a ds_read issued before the barrier but still queued in the LDS pipe lost against the returning DMA about once
+    // per 10^5 tiles at two workgroups per CU: s_barrier does not wait for lgkmcnt.)
+    constexpr int LEAD = NW - 1;
+    constexpr int WOUT = SPF ? LEAD - 2 : NW - 2;  // W tiles issued after the one a barrier needs
 #pragma unroll
     for (int t = 0; t < LEAD; ++t)
         if (t < nk) issue_w(t);
@@ -266,7 +269,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     bf16x8 wfc[TC], xfr[TP];                     // SPF: fragments of the step about to run
     if constexpr (SPF) {
         int ahead0 = nk - 1;
-        if (ahead0 > NW - 1) ahead0 = NW - 1;
+        if (ahead0 > LEAD - 1) ahead0 = LEAD - 1;
         wait_vmcnt(ahead0 * wpw);                // W(0) and X(0) landed (this wave's pieces) ...
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();            // ... and everybody else's
@@ -297,13 +300,13 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             // the operand needed at this barrier: W(t) -- or W(t+1) with SPF, whose fragments are read during
             // this step.  Ops issued after it: the next NW-2 weight tiles (+ the next halo inside its window).
             if constexpr (!LAST) {
-                int n = (NW - 2) * wpw;
-                if (XT == 0) { if (tap >= 1 && tap <= NW - 1) n += NXW; }                 // next halo, DMA'd at tap 0
+                int n = WOUT * wpw;
+                if (XT == 0) { if (tap >= 1 && tap <= LEAD - 1) n += NXW; }               // next halo, DMA'd at tap 0
                 else { for (int r = tap - (NW - 1); r <= tap - 1; ++r) if (r >= 0 && r < NXW) n += LX; }
                 wait_vmcnt(n);
             } else {
                 int ahead = nk - 1 - (SPF ? t + 1 : t);
-                if (ahead > NW - 2) ahead = NW - 2;
+                if (ahead > WOUT) ahead = WOUT;
                 if (ahead < 0) ahead = 0;
                 wait_vmcnt(ahead * wpw);
             }

@@ -128,6 +128,145 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv_in on the matrix cores (Cout == 128): the 27 taps x channels of each pixel become one K = 32 operand row
+// (im2col built in LDS from the fp32 halo, rounded to bf16), so the whole conv is ONE v_mfma_f32_16x16x32_bf16
+// K-step per 16x16 output tile; the kernel is then bound by its output write.  Workgroup = 4 waves, 8 rows x 64
+// pixels x 128 couts; LDS: fp32 halo 3 x 10 x 66, X rows 512 x 64 B, W rows 128 x 64 B (64-B-row swizzle as in
+// conv3x3_halo).  Weight rows use the interleaved cout map: lane (fq, fr) holds couts 64*h + 16*fq + 4*i + r
+// of pixel fr (tile i of half h), i.e. 16 consecutive couts per half -> 32-B fp16 / 64-B fp32 stores.
+// wpk: [128 rows][32 k] bf16 in that row order, k = ci*9 + ky*3 + kx, k >= 27 zero.
+constexpr int CM_ROWS = 8, CM_PIX = 64;
+__global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wpk,
+                                                           const float* __restrict__ bias, float* __restrict__ o32,
+                                                           bf16_t* __restrict__ o16, f16_t* __restrict__ oh,
+                                                           float* __restrict__ gn_partial, int H, int W) {
+    constexpr int RW = CM_PIX + 2, RH = CM_ROWS + 2, NPX = CM_ROWS * CM_PIX, C = 128;
+    __shared__ __attribute__((aligned(16))) float sin[3 * RH * RW];
+    __shared__ __attribute__((aligned(16))) char xs[NPX * 64];
+    __shared__ __attribute__((aligned(16))) char ws[C * 64];
+    __shared__ float red[4][32][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, y0 = blockIdx.y * CM_ROWS, x0 = blockIdx.x * CM_PIX;
+    // weights: 8 KB, 16 B per thread x 2, swizzled like every 64-B-row LDS image here
+    for (int i = tid; i < C * 4; i += 256) {
+        const int row = i >> 2, ch = i & 3;
+        *(bf16x8*)(ws + row * 64 + ((ch ^ (((row >> 2) & 1) << 1)) << 4)) = *(const bf16x8*)(wpk + row * 32 + ch * 8);
+    }
+    for (int i = tid; i < 3 * RH * RW; i += 256) {
+        const int c = i / (RH * RW), r = (i / RW) % RH, xx = i % RW;
+        const int iy = y0 - 1 + r, ix = x0 - 1 + xx;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long long)b * 3 + c) * H + iy) * W + ix];
+        sin[i] = v;
+    }
+    __syncthreads();
+    // im2col: pixel p = row*64 + col -> 32 bf16 (27 real), four 16-B chunks
+    for (int p = tid; p < NPX; p += 256) {
+        const int py = p >> 6, px = p & 63;
+        bf16_t v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k < 27) {
+                const int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
+                v[k] = (bf16_t)sin[(ci * RH + py + ky) * RW + px + kx];
+            } else v[k] = (bf16_t)0.f;
+        }
+        const int sw = ((p >> 2) & 1) << 1;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            bf16x8 h;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) h[r] = v[ch * 8 + r];
+            *(bf16x8*)(xs + p * 64 + ((ch ^ sw) << 4)) = h;
+        }
+    }
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    bf16x8 wf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 16 + fr;
+        wf[i] = *(const bf16x8*)(ws + row * 64 + ((fq ^ (((row >> 2) & 1) << 1)) << 4));
+    }
+    f32x4 bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = *(const f32x4*)(bias + 64 * (i >> 2) + 16 * fq + 4 * (i & 3));
+    float gs[8], gss[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gs[i] = gss[i] = 0.f;
+    int cnt = 0;
+    // wave w: tile rows 2w, 2w+1 (128 pixels = 8 pixel tiles)
+#pragma unroll 2
+    for (int t = 0; t < 8; ++t) {
+        const int p = wave * 128 + t * 16 + fr;                       // this lane's pixel in the tile
+        const bf16x8 xf = *(const bf16x8*)(xs + p * 64 + ((fq ^ (((p >> 2) & 1) << 1)) << 4));
+        const int y = y0 + (p >> 6), xx = x0 + (p & 63);
+        const bool ok = y < H && xx < W;
+        const long long o = (((long long)b * H + y) * W + xx) * C + 16 * fq;
+        f32x4 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf, bv[i], 0, 0, 0);
+        if (ok) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const long long oo = o + 64 * hh;
+                if (o32) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *(f32x4*)(o32 + oo + 4 * i) = acc[hh * 4 + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    if (oh) {
+                        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                        f16x8 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { h[r] = (f16_t)acc[hh * 4 + i][r]; h[4 + r] = (f16_t)acc[hh * 4 + i + 1][r]; }
+                        *(f16x8*)(oh + oo + 4 * i) = h;
+                    }
+                    if (o16) {
+                        bf16x8 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { h[r] = (bf16_t)acc[hh * 4 + i][r]; h[4 + r] = (bf16_t)acc[hh * 4 + i + 1][r]; }
+                        *(bf16x8*)(o16 + oo + 4 * i) = h;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = acc[i][r] - bv[i][0]; gs[i] += d; gss[i] = fmaf(d, d, gss[i]); }
+            ++cnt;
+        }
+    }
+    if (gn_partial) {
+        // 32 GroupNorm groups of 4 couts: group of (half h, fq, tile i) = 16*h + 4*fq + i.  Sums are relative to the
+        // group's first bias (E[x] ~ 0 makes that a good pivot); merge the 16 pixel columns, then the 4 waves.
+        float n = 4.0f * (float)cnt;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) n += __shfl_xor(n, o, 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float s1 = gs[i], s2 = gss[i];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if (fr == 0) {
+                const int g = 16 * (i >> 2) + 4 * fq + (i & 3);
+                const float ms = n > 0.f ? s1 / n : 0.f;
+                red[wave][g][0] = n; red[wave][g][1] = bv[i][0] + ms; red[wave][g][2] = n > 0.f ? fmaxf(s2 - s1 * ms, 0.f) : 0.f;
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float nn = 0.f, mean = 0.f, m2 = 0.f;
+            for (int w = 0; w < 4; ++w) vt_chan_merge(nn, mean, m2, red[w][tid][0], red[w][tid][1], red[w][tid][2]);
+            const int part = blockIdx.y * gridDim.x + blockIdx.x, nparts = gridDim.x * gridDim.y;
+            float* o = gn_partial + (((long long)b * nparts + part) * 32 + tid) * 3;
+            o[0] = nn; o[1] = mean; o[2] = m2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row softmax of the attention scores (fp32, or fp16 as the QK^T epilogue writes them) -> bf16 P, the operand of
 // the P.V GEMM.  One workgroup per row.  Pad columns [n, ldp) are written as zeros so the GEMM's 8-element
 // k-chunks never see garbage.
@@ -246,7 +385,70 @@ hipError_t vt_launch_conv_in(const float* x, const float* wp, const float* bias,
     return hipGetLastError();
 }
 
+hipError_t vt_launch_conv_in_mfma(const float* x, const bf16_t* wpk, const float* bias, float* o32, bf16_t* o16, f16_t* oh,
+                                  float* gn_partial, int* gn_parts, int B, int H, int W, hipStream_t s) {
+    if (!x || !wpk || !bias || (!o32 && !o16 && !oh) || B <= 0 || H <= 0 || W <= 0) return hipErrorInvalidValue;
+    dim3 grid((W + CM_PIX - 1) / CM_PIX, (H + CM_ROWS - 1) / CM_ROWS, B);
+    if (gn_parts) *gn_parts = grid.x * grid.y;
+    hipLaunchKernelGGL(conv_in_mfma_kernel, grid, dim3(256), 0, s, x, wpk, bias, o32, o16, oh, gn_partial, H, W);
+    return hipGetLastError();
+}
+int vt_conv_in_mfma_parts(int H, int W) { return ((W + CM_PIX - 1) / CM_PIX) * ((H + CM_ROWS - 1) / CM_ROWS); }
+
 int vt_conv_in_parts(int H, int W) { return ((W + CI_PIX - 1) / CI_PIX) * ((H + CI_ROWS - 1) / CI_ROWS); }
+
+// fp16 scores, 16-B loads and stores: thread t owns values [(k*256 + t)*8, +8) of the row, k < NV (n <= NV*2048).
+// Requires lds % 8 == 0, ldp % 8 == 0 and 16-B aligned bases.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_f16x8_kernel(const f16_t* __restrict__ s, bf16_t* __restrict__ p,
+                                                                 int n, int lds, int ldp) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    __shared__ float red[8];
+    const long long row = blockIdx.x;
+    const f16_t* sr = s + row * lds;
+    bf16_t* pr = p + row * ldp;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float v[NV][8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = (k * 256 + tid) * 8;
+        if (i + 7 < n) {
+            const f16x8 h = *(const f16x8*)(sr + i);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[k][r] = (float)h[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[k][r] = (i + r < n) ? (float)sr[i + r] : -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) m = fmaxf(m, v[k][r]);
+    }
+    m = wave_max(m);
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { v[k][r] = __expf(v[k][r] - m); sum += v[k][r]; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wv] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = (k * 256 + tid) * 8;
+        if (i < ldp) {
+            bf16x8 h;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) h[r] = (bf16_t)(v[k][r] * inv);
+            *(bf16x8*)(pr + i) = h;
+        }
+    }
+}
 
 template <typename T>
 static hipError_t softmax_dispatch(const T* scores, bf16_t* probs, long long rows, int n, int lds, int ldp, hipStream_t s) {
@@ -267,6 +469,15 @@ static hipError_t softmax_dispatch(const T* scores, bf16_t* probs, long long row
 hipError_t vt_launch_softmax_rows(const void* scores, int scores_f16, bf16_t* probs, long long rows, int n, int lds, int ldp,
                                   hipStream_t s) {
     if (!scores || !probs || rows <= 0 || rows > 0x7fffffffLL || n <= 0 || lds < n || ldp < n) return hipErrorInvalidValue;
+    if (scores_f16 && (lds % 8 == 0) && (ldp % 8 == 0) && (((uintptr_t)scores) % 16 == 0) && (((uintptr_t)probs) % 16 == 0) &&
+        ldp <= 8 * 2048) {
+        const int need = (ldp + 2047) / 2048;
+        const dim3 grid((unsigned)rows);
+#define SMH(NV) hipLaunchKernelGGL((softmax_rows_f16x8_kernel<NV>), grid, dim3(256), 0, s, (const f16_t*)scores, probs, n, lds, ldp)
+        if (need <= 1) SMH(1); else if (need <= 2) SMH(2); else if (need <= 4) SMH(4); else SMH(8);
+#undef SMH
+        return hipGetLastError();
+    }
     return scores_f16 ? softmax_dispatch((const f16_t*)scores, probs, rows, n, lds, ldp, s)
                       : softmax_dispatch((const float*)scores, probs, rows, n, lds, ldp, s);
 }

@@ -69,6 +69,10 @@ hipError_t vt_launch_conv_in(const float* x_nchw, const float* w_packed /*[27][C
                              float* out_f32, bf16_t* out_bf16, f16_t* out_f16, float* gn_partial, int gn_cpg, int* gn_parts,
                              int B, int H, int W, int Cout, hipStream_t s);
 int vt_conv_in_parts(int H, int W);
+// MFMA variant (Cout == 128, 32 GroupNorm groups): wpk = [128 rows][32 k] bf16, rows in the interleaved cout order
+hipError_t vt_launch_conv_in_mfma(const float* x_nchw, const bf16_t* wpk, const float* bias, float* out_f32, bf16_t* out_bf16,
+                                  f16_t* out_f16, float* gn_partial, int* gn_parts, int B, int H, int W, hipStream_t s);
+int vt_conv_in_mfma_parts(int H, int W);
 
 // x_dtype below: 0 = bf16, 1 = fp32, 2 = fp16.
 // GroupNorm statistics: x rows [B][HW][C] -> partial (count, mean, M2) per
