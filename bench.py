@@ -46,6 +46,7 @@ def parse():
     p.add_argument("--generic-conv", action="store_true", help="A/B: disable the halo-tile 3x3 kernel")
     p.add_argument("--cpu-sample-res", type=int, default=1024)
     p.add_argument("--no-occ2", action="store_true", help="A/B: 128-cout convs on the one-workgroup-per-CU tile")
+    p.add_argument("--flag", action="append", default=[], metavar="N=V", help="A/B: vt_set_flag(N, V) before the run (repeatable)")
     return p.parse_args()
 
 
@@ -113,6 +114,9 @@ def main():
         pipe.ctx.call("vt_set_flag", 0, 0)
     if a.no_occ2:
         pipe.ctx.call("vt_set_flag", 3, 0)
+    for fv in a.flag:
+        f, v = fv.split("=")
+        pipe.ctx.call("vt_set_flag", int(f), int(v))
 
     B = a.batch
     counts = [B] * world
