@@ -46,6 +46,7 @@ def parse():
     p.add_argument("--generic-conv", action="store_true", help="A/B: disable the halo-tile 3x3 kernel")
     p.add_argument("--cpu-sample-res", type=int, default=1024)
     p.add_argument("--no-occ2", action="store_true", help="A/B: 128-cout convs on the one-workgroup-per-CU tile")
+    p.add_argument("--lib", default=None, help="A/B: path of an alternative build of libvae_tagger_hip.so")
     p.add_argument("--flag", action="append", default=[], metavar="N=V", help="A/B: vt_set_flag(N, V) before the run (repeatable)")
     return p.parse_args()
 
@@ -72,6 +73,9 @@ def cpu_baseline(res, tags, flops_target):
 
 def main():
     a = parse()
+    if a.lib:
+        from vae_tagger_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     import torch
     import torch.distributed as dist
 

@@ -142,12 +142,12 @@ int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, C
     out->cin = cin; out->cout = cout; out->k = k;
     if (!out->w || !out->b) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
     if (k == 3 && vt_conv3x3_halo_supported(cin, cout)) {
-        // halo kernel: Wp[cin/32][tap][cout][32] so each K-step's weight tile is one contiguous block
+        // halo kernel: Wp[cin/32][step][cout][32] (step = kx*3 + ky) so each K-step's weight tile is one contiguous block
         std::vector<uint16_t> hp(p.size());
         for (int o = 0; o < cout; ++o)
             for (int t = 0; t < 9; ++t)
                 for (int i = 0; i < cin; ++i)
-                    hp[(((size_t)(i >> 5) * 9 + t) * cout + ((o & ~63) + vt_halo_row_of_cout(o & 63))) * 32 + (i & 31)] = p[((size_t)o * 9 + t) * cin + i];
+                    hp[(((size_t)(i >> 5) * 9 + vt_halo_step_of_tap(t)) * cout + ((o & ~63) + vt_halo_row_of_cout(o & 63))) * 32 + (i & 31)] = p[((size_t)o * 9 + t) * cin + i];
         out->wp = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
         if (!out->wp) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
     }

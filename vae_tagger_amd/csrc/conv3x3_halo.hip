@@ -13,8 +13,8 @@
 //     logical chunk ^ (((row >> 2) & 1) << 1), applied to the DMA's per-lane SOURCE address (the DMA
 //     destination is lane-linear) and again on the ds_read_b128 side.
 //
-// Weights are pre-packed on the host as Wp[chunk32][tap][Cout][32] bf16 so that every K-step's tile is
-// one contiguous BC*64-byte block.  MFMA orientation as in conv_gemm.hip: weights = A operand (rows =
+// Weights are pre-packed on the host as Wp[chunk32][step][Cout][32] bf16 (step = kx*3 + ky: dx-major) so that every
+// K-step's tile is one contiguous BC*64-byte block.  MFMA orientation as in conv_gemm.hip: weights = A operand (rows =
 // cout), pixels = B operand, so a lane holds 4 consecutive couts of one pixel.
 #include <type_traits>
 
@@ -168,9 +168,13 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             if (hx >= HWID) { hx -= HWID; ++hy; }
         }
     };
-    auto issue_w = [&](int t) {
+    // K-step t of the kernel -> weight tile in the (kx-major) packed order.  Every variant walks the taps kx-major except
+    // the 128-VGPR one, which walks them ky-major (fewer live fragment addresses) and permutes its weight fetches instead.
+    constexpr bool KYMAJOR = XT == 0 && TPW == 4;
+    auto issue_w = [&](int t, int tap_of_t /* t % 9, a compile-time constant at every call site */) {
         char* dst = wbase + (t % NW) * WBUF;
-        const bf16_t* wt = a.Wp + (long long)t * wstep + opaque(wsrc0);
+        const int src_t = KYMAJOR ? t - tap_of_t + vt_halo_step_of_tap(tap_of_t) : t;
+        const bf16_t* wt = a.Wp + (long long)src_t * wstep + opaque(wsrc0);
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
             if (WPCS % NLD == 0 || j * NLD + wave < WPCS)
@@ -264,9 +268,17 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     constexpr int WOUT = SPF ? LEAD - 2 : NW - 2;  // W tiles issued after the one a barrier needs
 #pragma unroll
     for (int t = 0; t < LEAD; ++t)
-        if (t < nk) issue_w(t);
+        if (t < nk) issue_w(t, t % 9);
 
-    bf16x8 wfc[TC], xfr[TP];                     // SPF: fragments of the step about to run
+    // SPF operands.  K-steps run dx-major (step p of a chunk: dx = p / 3, dy = p % 3; the weights are packed in that
+    // order), so the TP+2 halo rows a wave needs for one dx serve all three dy taps from REGISTERS: xr[r] = halo row r
+    // of the wave at column shift dx, and the MFMA for output row j at tap dy reads xr[j + dy].  LDS->register traffic
+    // for X falls from 9*TP to 3*(TP+2) fragments per chunk (72 -> 30 at TP = 8).  Row r is refilled with the NEXT
+    // group's row r as soon as its last reader has issued: row 0 after (dy 0, j 0), row 1 after (dy 1, j 0), row r >= 2
+    // after (dy 2, j = r-2).  The 128-VGPR variant (TPW = 4) has no room for the two extra fragments: it keeps one
+    // fragment per output row and re-reads it for every tap.
+    constexpr bool DYR = TPW == 8;
+    bf16x8 wfc[TC], xr[DYR ? TP + 2 : TP];
     if constexpr (SPF) {
         int ahead0 = nk - 1;
         if (ahead0 > LEAD - 1) ahead0 = LEAD - 1;
@@ -278,9 +290,9 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
 #pragma unroll
         for (int i = 0; i < TC; ++i) wfc[i] = *(const bf16x8*)(ws0 + i * 16 * HB);
 #pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const int rel = j * HWID;            // tap 0: dy = dx = 0
-            xfr[j] = *(const bf16x8*)(xbase + xaddr(rel & 7) + rel * HB);
+        for (int r = 0; r < (DYR ? TP + 2 : TP); ++r) {
+            const int rel = r * HWID;            // step 0: dx = dy = 0
+            xr[r] = *(const bf16x8*)(xbase + xaddr(rel & 7) + rel * HB);
         }
     }
 
@@ -315,16 +327,50 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             __builtin_amdgcn_s_barrier();        // all waves' pieces of the tile (and X(chunk)) are in LDS;
             asm volatile("" ::: "memory");       // everyone is done reading the stage that is refilled next
             if constexpr (!SPF) {
-                if (!LAST || t + LEAD < nk) issue_w(t + LEAD);
+                if (!LAST || t + LEAD < nk) issue_w(t + LEAD, (tap + LEAD) % 9);
             }
 
-            if constexpr (SPF) {
+            if constexpr (SPF && !DYR) {
                 // MFMAs of step t on registers filled during step t-1; meanwhile fetch step t+1's fragments
                 const bool has_next = !LAST || t + 1 < nk;
                 const int tap_n = (tap + 1) % 9;
-                const int dy_n = tap_n / 3, dx_n = tap_n % 3;
+                const int dy_n = tap_n / 3, dx_n = tap_n % 3;            // ky-major walk (KYMAJOR)
                 const char* xs_n = (tap == 8) ? xbase + ((chunk + 1) & 1) * XBUF : xs;
                 const char* ws_n = wbase + ((t + 1) % NW) * WBUF + opaque(wfoff);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+#pragma unroll
+                    for (int i = 0; i < TC; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[i], xr[j], acc[i][j], 0, 0, 0);
+                    if (has_next) {
+                        const int rel = (j + dy_n) * HWID + dx_n;
+                        xr[j] = *(const bf16x8*)(xs_n + xaddr(rel & 7) + rel * HB);     // its last reader has issued
+                    }
+                    if (j == TP / 2 - 1) {
+                        if (!LAST || t + LEAD < nk) issue_w(t + LEAD, (tap + LEAD) % 9);
+                        if constexpr (!LAST) { if (tap == 0) issue_x_dma(chunk + 1); }
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (has_next) {
+#pragma unroll
+                    for (int i = 0; i < TC; ++i) wfc[i] = *(const bf16x8*)(ws_n + i * 16 * HB);
+                }
+                continue;
+            }
+            if constexpr (SPF) {
+                // MFMAs of step t on registers filled earlier; meanwhile fetch the next group's halo rows / next step's W
+                const int dx = tap / 3, dy = tap % 3;
+                const bool has_next = !LAST || t + 1 < nk;                 // a next K-step exists (W fragments)
+                const bool next_group = !LAST || dx < 2;                   // a next dx group exists (X fragments)
+                const int dx_n = (dx + 1) % 3;
+                const char* xs_n = (dx == 2) ? xbase + ((chunk + 1) & 1) * XBUF : xs;
+                const char* ws_n = wbase + ((t + 1) % NW) * WBUF + opaque(wfoff);
+                auto refill = [&](int r) {                                 // DYR: halo row r of the next dx group
+                    const int rel = r * HWID + dx_n;
+                    xr[r] = *(const bf16x8*)(xs_n + xaddr(rel & 7) + rel * HB);
+                };
                 // An LDS-DMA piece costs its wave ~100 issue cycles.  Issued right after the barrier by all 8 waves
                 // at once, that kept the matrix pipe idle (~190 cycles per K-step, in-kernel stamps); instead each
                 // wave slips its pieces into the MIDDLE of its MFMA sequence.  The older wave of a SIMD pair wins MFMA
@@ -335,13 +381,14 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 for (int j = 0; j < TP; ++j) {
 #pragma unroll
                     for (int i = 0; i < TC; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[i], xfr[j], acc[i][j], 0, 0, 0);
-                    if (has_next) {
-                        const int rel = (j + dy_n) * HWID + dx_n;
-                        xfr[j] = *(const bf16x8*)(xs_n + xaddr(rel & 7) + rel * HB);     // its last reader has issued
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[i], xr[j + dy], acc[i][j], 0, 0, 0);
+                    if (next_group) {                                      // rows whose last reader has just issued
+                        if (dy == 0 && j == 0) refill(0);
+                        if (dy == 1 && j == 0) refill(1);
+                        if (dy == 2) refill(j + 2);
                     }
                     if (j == TP / 2 - 1) {
-                        if (!LAST || t + LEAD < nk) issue_w(t + LEAD);
+                        if (!LAST || t + LEAD < nk) issue_w(t + LEAD, (tap + LEAD) % 9);
                         if constexpr (!LAST) { if (tap == 0) issue_x_dma(chunk + 1); }
                     }
                 }
@@ -354,7 +401,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 continue;
             }
             const char* ws = wbase + (t % NW) * WBUF + opaque(wfoff);     // stage bases beyond 64 KB cannot be ds_read immediates
-            const int dy = tap / 3, dx = tap % 3;
+            const int dx = tap / 3, dy = tap % 3;          // dx-major K-step order (see the weight packers)
             bf16x8 wf[TC];
 #pragma unroll
             for (int i = 0; i < TC; ++i) wf[i] = *(const bf16x8*)(ws + i * 16 * HB);
@@ -501,7 +548,7 @@ __global__ void repack_ohwi_kernel(const bf16_t* __restrict__ w, bf16_t* __restr
     const int tap = (int)((i / Cin) % 9);
     const int co = (int)(i / ((long long)Cin * 9));
     const int row = (co & ~63) + vt_halo_row_of_cout(co & 63);      // interleaved cout map (see the kernel epilogue)
-    wp[(((long long)(ci >> 5) * 9 + tap) * Cout + row) * 32 + (ci & 31)] = w[i];
+    wp[(((long long)(ci >> 5) * 9 + vt_halo_step_of_tap(tap)) * Cout + row) * 32 + (ci & 31)] = w[i];
 }
 
 }  // namespace

