@@ -21,6 +21,27 @@
 #include "vt_common.h"
 #include "vt_kernels.h"
 
+#ifdef HALO_STAMP
+// Diagnostic build only (tools/stamp_halo.py): wall-clock stamps (s_memrealtime, 100 MHz) of the phases of one workgroup.
+__device__ unsigned long long* g_halo_stamps = nullptr;
+extern "C" int vt_debug_halo_stamps(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_halo_stamps), &buf, sizeof(buf));
+}
+#ifndef STAMP_TID
+#define STAMP_TID 0
+#endif
+#define STAMP(slot)                                                                                            \
+    do {                                                                                                       \
+        unsigned long long t_;                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (g_halo_stamps && threadIdx.x == STAMP_TID) g_halo_stamps[(long long)blockIdx.x * 16 + (slot)] = t_; \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int HB = 64;        // bytes per LDS row (32 bf16)
@@ -110,6 +131,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     // W DMA pieces THIS wave issues per K-step (the vmcnt arithmetic below is per wave)
     const int wpw = (WPCS % NLD == 0) ? WPW : (wave < WPCS % NLD ? WPW : WPW - 1);
 
+    STAMP(0);
     // ---- tile coordinates
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + ROWS - 1) / ROWS;
     const int ctiles = a.Cout / BC;
@@ -233,11 +255,15 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     for (int k = 0; k < 8; ++k)
         xsel[k] = (wp * TPW * HWID + fr) * HB + ((fq ^ ((((k + fr) >> 2) & 1) << 1)) << 4);
     auto xaddr = [&](int k) -> int { return xsel[k]; };        // k is a compile-time constant after unrolling
+    // accumulators start at the bias (cout map: tile i / register r of lane (fq, fr) = cout c0 + wc*64 + 16*fq + 4*i + r):
+    // the epilogue neither adds it nor holds it in registers (its VALU time is exposed: 2 waves per SIMD, nothing to hide under)
     f32x4 acc[TC][TP];
 #pragma unroll
-    for (int i = 0; i < TC; ++i)
+    for (int i = 0; i < TC; ++i) {
+        const f32x4 bv = a.bias ? *(const f32x4*)(a.bias + c0 + wc * 64 + 16 * fq + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TP; ++j) acc[i][j] = bv;
+    }
 
     // ---- prologue: X(0), then W(0..NW-2)
     if constexpr (XT == 0) {
@@ -279,6 +305,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     // fragment per output row and re-reads it for every tap.
     constexpr bool DYR = TPW == 8;
     bf16x8 wfc[TC], xr[DYR ? TP + 2 : TP];
+    STAMP(1);
     if constexpr (SPF) {
         int ahead0 = nk - 1;
         if (ahead0 > LEAD - 1) ahead0 = LEAD - 1;
@@ -295,6 +322,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             xr[r] = *(const bf16x8*)(xbase + xaddr(rel & 7) + rel * HB);
         }
     }
+    STAMP(2);
 
     // One chunk = 9 K-steps (taps).  LAST = the final chunk: no next halo, weight ring drains, so the
     // wait count is computed at run time; every other chunk's counts fold to immediates after unrolling.
@@ -454,6 +482,11 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     };
     for (int chunk = 0; chunk + 1 < nchunk; ++chunk) do_chunk(chunk, std::false_type{});
     do_chunk(nchunk - 1, std::true_type{});
+    STAMP(3);
+#ifdef HALO_STAMP
+    asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[TC - 1][TP - 1]));      // the last MFMA results have landed
+    STAMP(8);
+#endif
 
     // ---- epilogue.  Weight rows are packed so that MFMA tile i / accumulator register r of lane (fq, fr) is
     // cout cw + 16*fq + 4*i + r: a lane owns 16 CONSECUTIVE couts of pixel (y, x = tx0 + fr) -> 16-B stores, and the
@@ -462,9 +495,6 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     const long long ob = (long long)b * HWp * a.Cout;
     const int x = tx0 + fr;
     const int cw = c0 + wc * 64 + 16 * fq;               // first of this lane's 16 couts
-    f32x4 bv[TC];
-#pragma unroll
-    for (int i = 0; i < TC; ++i) bv[i] = a.bias ? *(const f32x4*)(a.bias + cw + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned valid = 0;
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
@@ -474,7 +504,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
         const long long o = ob + ((long long)y * a.W + x) * a.Cout + cw;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
-            f32x4 v = acc[i][j] + bv[i];
+            f32x4 v = acc[i][j];
             if (a.res) v += *(const f32x4*)(a.res + o + 4 * i);
             if (a.out_f32) *(f32x4*)(a.out_f32 + o + 4 * i) = v;
             acc[i][j] = v;
@@ -505,17 +535,34 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 bf16x8 h;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { h[r] = (bf16_t)acc[i][j][r]; h[4 + r] = (bf16_t)acc[i + 1][j][r]; }
+#ifdef EPI_NOSTORE
+                asm volatile("" :: "v"(h));
+#else
                 *(bf16x8*)(a.out_bf16 + o + 4 * i) = h;
+#endif
             }
         }
     }
+    STAMP(4);
     if (a.gn_partial) {
         // GroupNorm statistics of this tile's outputs for the NEXT layer's norm (replaces a full read pass)
         __syncthreads();                                   // every wave is done with the staging LDS
+        STAMP(10);
         const int G = a.Cout / a.gn_cpg;
         float* out = a.gn_partial + (((long long)b * (tiles_x * tiles_y) + tile) * G + c0 / a.gn_cpg) * 3;
         vt_gn_epilogue_partials_il<TC, TP>(acc, valid, a.gn_cpg, wp, WP, wc * 64, BC, (float*)smem, out);
     }
+#ifdef HALO_STAMP
+    STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(6);
+    if (g_halo_stamps && threadIdx.x == STAMP_TID) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_halo_stamps[(long long)blockIdx.x * 16 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 template <int WP, int WC, int XT, int TPW, int NW = NW_DEFAULT>

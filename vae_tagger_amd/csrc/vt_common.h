@@ -109,6 +109,18 @@ __device__ __forceinline__ void vt_gn_epilogue_partials(const f32x4 (&v)[TC][TP]
     }
 }
 
+// Sum over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane of the row.  Four v_add_f32 with DPP
+// operands (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) instead of four ds_bpermute round trips:
+// after the two quad steps every lane of a quad holds the quad's sum, so mirroring within 8 and then within 16 lanes pairs
+// disjoint partial sums.
+__device__ __forceinline__ float vt_row16_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+    return x;
+}
+
 // Variant for the "interleaved" cout map of conv3x3_halo: a lane's registers hold 16 CONSECUTIVE couts of its pixel,
 // cout = wave_cout0 + 16*fq + 4*i + r (tile i, register r), so every GroupNorm group (4, 8 or 16 channels) lives in
 // ONE lane; only the 16 pixel columns (fr) are merged across lanes.
@@ -117,33 +129,56 @@ __device__ __forceinline__ void vt_gn_epilogue_partials_il(const f32x4 (&v)[TC][
                                                            int nwp, int wave_cout0, int block_couts, float* lds,
                                                            float* out) {
     static_assert(TC == 4, "interleaved map covers 16 couts per lane");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
     const int fr = lane & 15, fq = lane >> 4;
     const int gpb = block_couts / cpg;
-    const float nl = 4.0f * (float)__popc(valid);
     const int tpg = cpg >> 2;                      // tiles (4-cout register groups) per GroupNorm group: 1, 2 or 4
+    // values per group in this lane's 16-lane row: 4 channels x tpg tiles x (valid pixels of the row); the pixel count is
+    // the same for every fq, so one ballot of the per-lane row masks gives it without shuffling floats
+    float n = 0.f;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const unsigned long long m = __ballot((valid >> j) & 1u);
+        n += (float)__popcll(m & 0xffffull);       // lanes 0..15 = the 16 pixel columns (identical for all four fq rows)
+    }
+    n *= 4.0f * (float)tpg;
+    const bool full = __ballot(valid != (1u << TP) - 1u) == 0ull;       // every pixel of the wave's tile is inside the image
 #pragma unroll
     for (int g0 = 0; g0 < TC; ++g0) {
         if (g0 % tpg) continue;                    // g0 = first tile of a group
         const float piv = __shfl(v[g0][0][0], lane & 48, 64);
-        float s = 0.f, ss = 0.f;
+        const f32x2 p2 = {piv, piv};
+        f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};    // two accumulators per sum: packed adds / fmas (v_pk_add_f32, v_pk_fma_f32)
+        if (full) {                                // the common case: no per-row execution masks
 #pragma unroll
-        for (int i = g0; i < TC; ++i) {
-            if (i >= g0 + tpg) break;
+            for (int i = g0; i < TC; ++i) {
+                if (i >= g0 + tpg) break;
 #pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                if ((valid >> j) & 1u) {
+                for (int j = 0; j < TP; ++j) {
+                    const f32x2 d0 = f32x2{v[i][j][0], v[i][j][1]} - p2, d1 = f32x2{v[i][j][2], v[i][j][3]} - p2;
+                    s2 += d0; q2 += d0 * d0;
+                    s2 += d1; q2 += d1 * d1;
+                }
+            }
+        } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float d = v[i][j][r] - piv; s += d; ss = fmaf(d, d, ss); }
+            for (int i = g0; i < TC; ++i) {
+                if (i >= g0 + tpg) break;
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    if ((valid >> j) & 1u) {
+                        const f32x2 d0 = f32x2{v[i][j][0], v[i][j][1]} - p2, d1 = f32x2{v[i][j][2], v[i][j][3]} - p2;
+                        s2 += d0; q2 += d0 * d0;
+                        s2 += d1; q2 += d1 * d1;
+                    }
                 }
             }
         }
-        float n = nl * (float)tpg;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); n += __shfl_xor(n, o, 64); }
-        float mean = 0.f, m2 = 0.f;
-        if (n > 0.f) { const float ms = s / n; mean = piv + ms; m2 = fmaxf(ss - s * ms, 0.f); }
+        const float s = vt_row16_sum(s2[0] + s2[1]), ss = vt_row16_sum(q2[0] + q2[1]);
         if (fr == 0) {
+            float mean = 0.f, m2 = 0.f;
+            if (n > 0.f) { const float ms = s / n; mean = piv + ms; m2 = fmaxf(ss - s * ms, 0.f); }
             const int lg = (wave_cout0 + 16 * fq + 4 * g0) / cpg;
             float* d = lds + (wp * gpb + lg) * 3;
             d[0] = n; d[1] = mean; d[2] = m2;
@@ -151,13 +186,13 @@ __device__ __forceinline__ void vt_gn_epilogue_partials_il(const f32x4 (&v)[TC][
     }
     __syncthreads();
     if ((int)threadIdx.x < gpb) {
-        float n = 0.f, mean = 0.f, m2 = 0.f;
+        float nn = 0.f, mean = 0.f, m2 = 0.f;
         for (int w = 0; w < nwp; ++w) {
             const float* d = lds + (w * gpb + threadIdx.x) * 3;
-            vt_chan_merge(n, mean, m2, d[0], d[1], d[2]);
+            vt_chan_merge(nn, mean, m2, d[0], d[1], d[2]);
         }
         float* o = out + threadIdx.x * 3;
-        o[0] = n; o[1] = mean; o[2] = m2;
+        o[0] = nn; o[1] = mean; o[2] = m2;
     }
 }
 
