@@ -117,7 +117,8 @@ def test_conv_epilogue_groupnorm_statistics(ops, conv_kernel, B, Cin, Cout, H, W
 
 
 @pytest.mark.parametrize("batch,M,N,K", [(1, 300, 200, 512), (2, 64, 512, 128), (1, 257, 108, 72), (1, 100, 104, 1000),
-                                            (1, 300, 200, 8), (1, 130, 260, 40), (2, 64, 300, 96), (1, 256, 256, 2048), (1, 520, 516, 168)])
+                                            (1, 300, 200, 8), (1, 130, 260, 40), (2, 64, 300, 96), (1, 256, 256, 2048), (1, 520, 516, 168),
+                                            (2, 200, 384, 512), (1, 385, 256, 72)])
 def test_gemm_nt_matches_torch(ops, batch, M, N, K):
     a = bf16_round(_rand((batch, M, K), 5))
     b = bf16_round(_rand((batch, N, K), 6, K ** -0.5))

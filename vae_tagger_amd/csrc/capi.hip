@@ -284,7 +284,7 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     a.x_bs = (long long)Hin * Win * w.cin; a.w_bs = 0; a.o_bs = (long long)Hout * Wout * w.cout; a.r_bs = a.o_bs;
     a.batch = B; a.alpha = 1.f; a.bias_mode = 1; a.out_mode = 0;
     if (fuse && w.cout > 32 && (w.cout % (w.cout <= 128 ? 128 : 256)) == 0) {
-        a.gn_partial = gn->partial; a.gn_cpg = cpg; gn->parts = vt_conv_gemm_ptiles(Hout * Wout, w.cout);
+        a.gn_partial = gn->partial; a.gn_cpg = cpg; gn->parts = vt_conv_gemm_ptiles_of(a);
     }
     HIPCK(c, launch_gemm(c, a, s), "conv_gemm");
     return VT_OK;
@@ -385,7 +385,7 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
         gn->parts = 0;
         const int cpg = C / groups;
         if (c->fuse_gn_stats && (cpg == 4 || cpg == 8 || cpg == 16) && C > 32 && (C % (C <= 128 ? 128 : 256)) == 0) {
-            a.gn_partial = gn->partial; a.gn_cpg = cpg; gn->parts = vt_conv_gemm_ptiles(S, C);
+            a.gn_partial = gn->partial; a.gn_cpg = cpg; gn->parts = vt_conv_gemm_ptiles_of(a);
         }
     }
     HIPCK(c, launch_gemm(c, a, s), "attn out proj");
@@ -867,6 +867,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 3) { vt_conv3x3_halo_set_occ2(value); return VT_OK; }       // process-wide: halo kernel geometry
     if (flag == 4) { c->res_fp16 = value != 0; return VT_OK; }
     if (flag == 5) { c->conv_in_mfma = value != 0; return VT_OK; }
+    if (flag == 6) { vt_conv_gemm_set_short(value); return VT_OK; }         // process-wide: GEMM tile choice
     return c->fail(VT_ERR_INVALID, "vt_set_flag: unknown flag %d", flag);
 }
 

@@ -28,8 +28,10 @@ namespace {
 constexpr int BK = 64;            // k-values per K-step (128-B LDS rows)
 constexpr int ROWB = BK * 2;      // bytes per LDS row
 
-template <int BP, int BC, int WP, int WC>
-__global__ __launch_bounds__(512) void conv_gemm_kernel(const ConvGemmArgs a) {
+// OCC2: compiled for two workgroups per CU (<= 128 VGPRs; the launcher checks the LDS fits twice): the latency-bound
+// short-K launches (1x1 shortcuts, attention projections, Q.K^T) overlap one workgroup's prologue / epilogue with the other's MFMAs.
+template <int BP, int BC, int WP, int WC, bool OCC2 = false>
+__global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const ConvGemmArgs a) {
     static_assert(WP * WC == 8, "8 waves per workgroup");
     constexpr int TP = BP / WP / 16;          // 16-pixel MFMA tiles per wave
     constexpr int TC = BC / WC / 16;          // 16-cout MFMA tiles per wave
@@ -227,11 +229,12 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const ConvGemmArgs a) {
     }
 }
 
-template <int BP, int BC, int WP, int WC>
+template <int BP, int BC, int WP, int WC, bool OCC2 = false>
 hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BP + BC) * ROWB;
+    static_assert(!OCC2 || smem <= 80 * 1024, "two workgroups per CU");
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<BP, BC, WP, WC>;
+    auto kern = conv_gemm_kernel<BP, BC, WP, WC, OCC2>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
@@ -268,22 +271,41 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
     switch (vt_conv_gemm_config(a)) {
         case 0: return launch_cfg<128, 32, 8, 1>(a, s);
         case 1: return launch_cfg<256, 128, 4, 2>(a, s);
+        case 9: return launch_cfg<192, 128, 4, 2, true>(a, s);
         default: return launch_cfg<256, 256, 2, 4>(a, s);
     }
 }
 
+// upper bound of the pixel tiles (= GroupNorm partials per image) any configuration uses for this Cout: buffer sizing
 int vt_conv_gemm_ptiles(int HWo, int Cout) {
-    const int bp = Cout <= 32 ? 128 : 256;
+    const int bp = Cout <= 32 ? 128 : (Cout <= 128 ? 192 : 256);
     return (HWo + bp - 1) / bp;
 }
+// the pixel tiles of THIS launch
+int vt_conv_gemm_ptiles_of(const ConvGemmArgs& a) {
+    const int cfg = vt_conv_gemm_config(a);
+    const int bp = cfg == 0 ? 128 : (cfg == 9 ? 192 : 256);
+    return (a.Hout * a.Wout + bp - 1) / bp;
+}
 
-int vt_conv_gemm_config(const ConvGemmArgs& a) { return a.Cout <= 32 ? 0 : (a.Cout <= 128 ? 1 : 2); }
+int g_gemm_short = 1;      // short-K launches without a statistics epilogue use the two-workgroups-per-CU tile (vt_set_flag 6)
+void vt_conv_gemm_set_short(int on) { g_gemm_short = on != 0; }
+
+int vt_conv_gemm_config(const ConvGemmArgs& a) {
+    if (a.Cout <= 32) return 0;
+    // the 128-cout stride-2 conv (18 K-steps per tile) gains the same way from a second resident workgroup
+    if (a.Cout == 128 && g_gemm_short && a.ksize == 3 && a.out_mode == 0) return 9;
+    if (a.Cout <= 128) return 1;
+    // 1x1 / GEMM launches with K <= 512 spend most of a 256x256 tile's life in its prologue and epilogue
+    if (g_gemm_short && a.ksize == 1 && a.Cin <= 512 && !a.gn_partial && (a.Cout % 128) == 0 && a.out_mode == 0) return 9;
+    return 2;
+}
 const char* vt_conv_gemm_config_name(int cfg) {
     static const char* n[VT_NUM_PROF_SLOTS] = {"conv_gemm_kernel<128,32,8,1>", "conv_gemm_kernel<256,128,4,2>",
                                                "conv_gemm_kernel<256,256,2,4>", "conv3x3_halo_kernel<4,2,0,4,4>",
                                                "conv3x3_halo_kernel<2,4,0,8,6>", "conv3x3_halo_kernel<4,2,1,8,6>",
                                                "conv3x3_halo_kernel<2,4,1,8,6>", "conv3x3_halo_kernel<4,2,2,8,6>",
-                                               "conv3x3_halo_kernel<2,4,2,8,6>", "gn_apply_kernel"};
+                                               "conv3x3_halo_kernel<2,4,2,8,6>", "conv_gemm_kernel<192,128,4,2,occ2>", "gn_apply_kernel"};
     if (cfg == 3 && !vt_conv3x3_halo_occ2()) return "conv3x3_halo_kernel<4,2,0,8,6>";
     return (cfg >= 0 && cfg < VT_NUM_PROF_SLOTS) ? n[cfg] : "?";
 }

@@ -33,9 +33,10 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s);
 // which tile configuration the dispatcher picks for these args: 0 = 128x32, 1 = 256x128, 2 = 256x256
 int vt_conv_gemm_config(const ConvGemmArgs& a);
 const char* vt_conv_gemm_config_name(int cfg);
-constexpr int VT_NUM_MFMA_CONFIGS = 9;   // 0..2 conv_gemm tiles, 3..8 conv3x3_halo <tile, XT>
-constexpr int VT_PROF_GN_APPLY = 9;      // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES
-constexpr int VT_NUM_PROF_SLOTS = 10;
+constexpr int VT_NUM_MFMA_CONFIGS = 10;  // 0..2 conv_gemm tiles, 3..8 conv3x3_halo <tile, XT>, 9 conv_gemm two-workgroups-per-CU tile
+constexpr int VT_PROF_GN_APPLY = 10;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES
+constexpr int VT_NUM_PROF_SLOTS = 11;
+void vt_conv_gemm_set_short(int on);     // short-K launches: two-workgroups-per-CU tile (default on)
 
 // 3x3 stride-1 pad-1 conv, halo-tile kernel (conv3x3_halo.hip)
 struct Conv3x3Args {
@@ -55,7 +56,8 @@ struct Conv3x3Args {
     int batch, H, W, Cin, Cout;
 };
 int vt_conv3x3_halo_tiles(int H, int W, int Cout, int fused_norm);   // GroupNorm partials per image the epilogue writes
-int vt_conv_gemm_ptiles(int HWo, int Cout);
+int vt_conv_gemm_ptiles(int HWo, int Cout);        // upper bound over configurations (buffer sizing)
+int vt_conv_gemm_ptiles_of(const ConvGemmArgs& a);  // of this launch (GroupNorm partials per image its epilogue writes)
 bool vt_conv3x3_halo_supported(int Cin, int Cout);
 void vt_conv3x3_halo_set_occ2(int on);   // 128-cout layers: 2-workgroups-per-CU tile (default on)
 int vt_conv3x3_halo_occ2(void);
