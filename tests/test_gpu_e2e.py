@@ -181,3 +181,40 @@ def test_device_preprocess_is_bit_exact_with_totensor_normalize(vae):
     ref = (u8.permute(0, 3, 1, 2).to(torch.float32).div(255.0) - 0.5) / 0.5       # ToTensor + Normalize(0.5, 0.5)
     got = pipe.normalize_u8(u8.cuda()).cpu()
     assert torch.equal(got, ref)
+
+
+def test_evaluation_caller_matches_oracle(vae, tmp_path):
+    """evaluate_model / find_optimal_threshold (reference evaluation.py:173-275) over a synthetic loader: probabilities come
+    from the HIP path, the expected metrics from the CPU oracle's probabilities through the same evaluator."""
+    import json
+    from vae_tagger_amd.evaluation import MultiLabelEvaluator, evaluate_model, find_optimal_threshold
+    n_tags = 11
+    dec = _decoder(n_tags)
+    sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(n_tags), seed=1)
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for i in range(3):
+        x = synth.synth_images(2, 64, 64, seed=40 + i)
+        batches.append({"pixel_values": x, "labels": (torch.rand(2, n_tags, generator=g) < 0.4).float()})
+    names = [f"tag_{i:05d}" for i in range(n_tags)]
+    probs = [torch.sigmoid(decoder_ref.attention_decoder_forward(sd_d, encoder_ref.vae_wrapper_encode(sd_e, b["pixel_values"])))
+             for b in batches]
+    # a threshold no oracle probability comes close to (the HIP logits are within 1e-2 of the oracle's, not equal)
+    flat = torch.cat([p.flatten() for p in probs]).sort().values
+    gaps = flat[1:] - flat[:-1]
+    k = int(gaps.argmax())
+    thr = float((flat[k] + flat[k + 1]) / 2)
+    assert gaps[k] > 1e-2
+    m = evaluate_model(vae, dec, batches, names, device="cuda", threshold=thr, output_dir=str(tmp_path))
+    ref = MultiLabelEvaluator(names, "cpu")
+    for b, p in zip(batches, probs):
+        ref.update((p > thr).float(), b["labels"], p)
+    want = ref.compute_metrics(thr)
+    for k in ("accuracy", "hamming_loss", "f1_micro", "f1_macro", "precision_weighted", "recall_micro"):
+        assert abs(m[k] - want[k]) < 1e-6, k
+    assert abs(m["mAP"] - want["mAP"]) < 5e-2          # ranks of near-tied probabilities may swap within the bf16 tolerance
+    assert json.load(open(tmp_path / "evaluation_results_overall.json"))["f1_micro"] == m["f1_micro"]
+    assert (tmp_path / "evaluation_results.csv").read_text().splitlines()[0] == "class_name,precision,recall,f1,ap,support"
+    r = find_optimal_threshold(vae, dec, batches, names, device="cuda", output_dir=str(tmp_path))
+    assert 0.1 <= r["global_threshold"] < 0.9 and set(r["per_class_thresholds"]) == set(names)

@@ -114,3 +114,42 @@ def test_sharded_logits_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_evaluation_metrics_match_scikit_learn():
+    """vae_tagger_amd.evaluation computes its metrics from confusion counts and a rank-based AP; scikit-learn (what the
+    reference calls per class, evaluation.py:58-72) is the checker."""
+    import numpy as np
+    from sklearn.metrics import average_precision_score, f1_score, precision_score, recall_score
+    from vae_tagger_amd.evaluation import MultiLabelEvaluator
+    rng = np.random.default_rng(0)
+    n, c = 300, 7
+    y_true = (rng.random((n, c)) < np.array([0.5, 0.1, 0.9, 0.3, 0.02, 0.6, 0.4])).astype(np.float32)
+    y_prob = np.clip(0.55 * y_true + 0.6 * rng.random((n, c)), 0, 1).astype(np.float32)
+    y_prob[:, 3] = np.round(y_prob[:, 3], 1)                 # many tied scores
+    y_pred = (y_prob > 0.5).astype(np.float32)
+    ev = MultiLabelEvaluator([f"t{i}" for i in range(c)], device="cpu")
+    for lo in range(0, n, 64):                                # several batches
+        ev.update(torch.from_numpy(y_pred[lo:lo + 64]), torch.from_numpy(y_true[lo:lo + 64]), torch.from_numpy(y_prob[lo:lo + 64]))
+    m = ev.compute_metrics(0.5)
+    for avg in ("micro", "macro", "weighted"):
+        assert abs(m[f"precision_{avg}"] - precision_score(y_true, y_pred, average=avg, zero_division=0)) < 1e-9
+        assert abs(m[f"recall_{avg}"] - recall_score(y_true, y_pred, average=avg, zero_division=0)) < 1e-9
+        assert abs(m[f"f1_{avg}"] - f1_score(y_true, y_pred, average=avg, zero_division=0)) < 1e-9
+    assert abs(m["mAP"] - average_precision_score(y_true, y_prob, average="macro")) < 1e-6
+    assert abs(m["mAP_micro"] - average_precision_score(y_true, y_prob, average="micro")) < 1e-6
+    assert abs(m["mAP_weighted"] - average_precision_score(y_true, y_prob, average="weighted")) < 1e-6
+    assert abs(m["accuracy"] - (y_true == y_pred).all(1).mean()) < 1e-12
+    assert abs(m["hamming_loss"] - (y_true != y_pred).mean()) < 1e-12
+    for i in range(c):
+        pc = m["per_class"][f"t{i}"]
+        assert abs(pc["ap"] - average_precision_score(y_true[:, i], y_prob[:, i])) < 1e-6
+        assert abs(pc["f1"] - f1_score(y_true[:, i], y_pred[:, i], zero_division=0)) < 1e-9
+        assert pc["support"] == int(y_true[:, i].sum())
+    # the reference's conventions for degenerate classes: no positive sample -> zeros; every sample positive -> AP 1
+    yt = y_true.copy(); yt[:, 0] = 0; yt[:, 1] = 1
+    ev.reset_metrics(); ev.update(y_pred, yt, y_prob)
+    m2 = ev.compute_metrics(0.5)
+    assert m2["per_class"]["t0"] == {"precision": 0.0, "recall": 0.0, "f1": 0.0, "ap": 0.0, "support": 0}
+    assert m2["per_class"]["t1"]["ap"] == 1.0 and m2["per_class"]["t1"]["recall"] == 1.0
+    assert m2["mAP"] == 0.0                                  # scikit-learn raises / warns here; the reference reports 0
