@@ -89,8 +89,9 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         0 = every GroupNorm runs its own statistics pass.
  * flag 2: 1 = GroupNorm-apply + SiLU in front of a 3x3 stride-1 conv runs inside that conv's halo staging,
  *         0 (default) = as a standalone HBM-bound pass (one read + one bf16 write of the tensor).
- * flag 3: 1 (default) = 128-cout 3x3 convs use the 16x16-pixel tile that lets two workgroups share a CU,
- *         0 = the 32x16-pixel one-workgroup-per-CU tile (process-wide).
+ * flag 3: two-workgroups-per-CU tiles of the halo conv (process-wide): 3 (default) = every plain-input layer on the
+ *         4-wave x 256-VGPR tile (16x16 px x 128 couts), 2 = only the 128-cout layers on it, 1 = the 128-cout layers on
+ *         the 8-wave x 128-VGPR tile, 0 = one workgroup per CU (16x16 px x 256 couts / 32x16 px x 128 couts).
  * flag 4: 1 (default) = the residual stream between resnet blocks is STORED as fp16 (all arithmetic stays fp32;
  *         halves the HBM traffic of the conv2 epilogues and of norm1), 0 = stored as fp32.
  * flag 5: 1 (default) = conv_in (3 -> 128 channels) runs on the matrix cores from a bf16 im2col operand,

@@ -38,4 +38,4 @@ for Cout, shape in ((256, (16, 512, 512)), (128, (8, 1024, 1024))):
         for Cin in (64, 128, 256, 512, 1024):
             print(f"occ2 {occ2}: ", end="")
             run(shape[0], shape[1], shape[2], Cin, Cout, occ2, iters=5)
-ctx.call("vt_set_flag", 3, 1)
+ctx.call("vt_set_flag", 3, 3)

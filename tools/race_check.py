@@ -24,8 +24,8 @@ for (B, H, W, Cin, Cout) in ((2, 1024, 1024, 128, 128), (2, 512, 512, 256, 256),
              vp(gam), vp(bet), vp(ss), vp(ws), None)
     torch.cuda.synchronize()
     base_o, base_ss = o32.clone(), ss.clone()          # the one-workgroup-per-CU tile
-    for occ2 in (1, 0):
-        if Cout != 128 and occ2: continue
+    for occ2 in (3, 2, 1, 0):
+        if Cout != 128 and occ2 in (1, 2): continue
         ctx.call("vt_set_flag", 3, occ2)
         def run():
             ctx.call("vt_op_conv2d_gn", vp(x), vp(w), vp(b), None, vp(o32), None, B, H, W, Cin, Cout, 3, 1, 1, 1, 32, 1e-6,
@@ -51,4 +51,4 @@ for (B, H, W, Cin, Cout) in ((2, 1024, 1024, 128, 128), (2, 512, 512, 256, 256),
         dss = (ref_ss - base_ss).abs().max().item()
         print(f"B{B} {H}x{W} {Cin}->{Cout} occ2={occ2}: {bad}/{reps} reps differ ({badpix} elems)  {ms:.3f} ms/op  "
               f"== baseline kernel: {same} (|d scale/shift| {dss:.2e})", flush=True)
-ctx.call("vt_set_flag", 3, 1)
+ctx.call("vt_set_flag", 3, 3)

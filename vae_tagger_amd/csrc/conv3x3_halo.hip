@@ -103,7 +103,8 @@ __global__ __launch_bounds__(64 * WP * WC, TPW == 4 ? 4 : 2)
 void conv3x3_halo_kernel(const Conv3x3Args a) {
     constexpr int NWV = WP * WC;                 // waves per workgroup
     constexpr int NT = 64 * NWV;
-    static_assert(NWV == 8 && (TPW == 8 || (TPW == 4 && XT == 0)), "8 waves x 8 rows, or 8 waves x 4 rows (two workgroups per CU)");
+    static_assert((NWV == 8 && (TPW == 8 || (TPW == 4 && XT == 0))) || (NWV == 4 && TPW == 8 && XT == 0),
+                  "8 waves x 8 rows, 8 waves x 4 rows (two workgroups per CU), or 4 waves x 8 rows (two workgroups per CU)");
     constexpr int ROWS = WP * TPW;               // tile rows (each wave: TPW rows x 16 px)
     constexpr int BC = WC * 64;                  // couts per workgroup (each wave: 64)
     constexpr int TP = TPW, TC = 4;
@@ -606,7 +607,12 @@ hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w, bf16_t* wp, int Cin, i
     return hipGetLastError();
 }
 
-int g_halo_occ2 = 1;       // 128-cout layers use the 2-workgroups-per-CU tile (vt_set_flag(ctx, 3, 0) turns it off)
+// Two-workgroups-per-CU tiles for plain-input layers (vt_set_flag(ctx, 3, mode)): while one workgroup runs its prologue /
+// epilogue (~12 us of VALU, latency and stores per tile) the other one has the matrix pipes.
+//   0 off; 1 = 128-cout layers on 8 waves x 128 VGPRs (16x16 px x 128 couts, wave tile 64 px x 64 couts);
+//   2 = 128-cout layers on 4 waves x 256 VGPRs (same tile, wave tile 128 px x 64 couts, halo rows reused across ky);
+//   3 = mode 2 for EVERY plain-input layer (256-cout layers run two 128-cout tiles per pixel tile).
+int g_halo_occ2 = 3;
 
 int vt_conv3x3_halo_tiles(int H, int W, int Cout, int fused_norm) {
     // must match the tile the dispatcher below picks: 256-cout tiles have 16 rows; 128-cout tiles 16 rows in the
@@ -615,7 +621,7 @@ int vt_conv3x3_halo_tiles(int H, int W, int Cout, int fused_norm) {
     return ((W + TW - 1) / TW) * ((H + rows - 1) / rows);
 }
 
-void vt_conv3x3_halo_set_occ2(int on) { g_halo_occ2 = on != 0; }
+void vt_conv3x3_halo_set_occ2(int mode) { g_halo_occ2 = mode < 0 ? 0 : (mode > 3 ? 3 : mode); }
 int vt_conv3x3_halo_occ2(void) { return g_halo_occ2; }
 
 bool vt_conv3x3_halo_supported(int Cin, int Cout) { return Cin >= 32 && (Cin % 32) == 0 && (Cout % 128) == 0; }
@@ -637,6 +643,7 @@ hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
     if (xt == 1 ? (a.X != nullptr) : (a.X == nullptr || a.Xf32 != nullptr)) return hipErrorInvalidValue;
     const bool big = (a.Cout % 256) == 0;                   // 16x16 px x 256 couts, else 32x16 px x 128 couts
     if (xt == 0) {
+        if (g_halo_occ2 == 3 || (g_halo_occ2 == 2 && !big)) return launch<2, 2, 0, 8, 4>(a, s);   // 4 waves, 2 workgroups / CU
         if (g_halo_occ2 && !big) return launch<4, 2, 0, 4, 4>(a, s);           // 16x16 px x 128 couts, 2 workgroups / CU
         return big ? launch<2, 4, 0, 8>(a, s) : launch<4, 2, 0, 8>(a, s);
     }
