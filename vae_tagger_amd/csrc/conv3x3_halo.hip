@@ -15,7 +15,7 @@
 //
 // Weights are pre-packed on the host as Wp[chunk32][step][Cout][32] bf16 (step = kx*3 + ky: dx-major) so that every
 // K-step's tile is one contiguous BC*64-byte block.  MFMA orientation as in conv_gemm.hip: weights = A operand (rows =
-// cout), pixels = B operand, so a lane holds 4 consecutive couts of one pixel.
+// cout), pixels = B operand; the packed cout rows are interleaved so that a lane holds 16 consecutive couts of one pixel.
 #include <type_traits>
 
 #include "vt_common.h"
@@ -95,9 +95,13 @@ __device__ __forceinline__ void wait_vmcnt_tied1(int n, V& r0) {
 //      hand-counted inline-asm global loads, GroupNorm'ed with the per-(image, channel) (scale, shift) the
 //      previous layer's epilogue statistics produced, SiLU'ed, rounded to bf16 and written to LDS -- the
 //      standalone GroupNorm+SiLU pass (one read + one write of the whole tensor) disappears.
-// TPW = tile rows per wave: 8 (wave tile 128 px x 64 couts, <= 256 VGPRs, one workgroup per CU) or 4 (see OCC2 below).
-// NW = weight ring depth.  OCC2 variants (8 waves x 4 rows, NW = 4): <= 128 VGPRs and <= 80 KB LDS so TWO workgroups
-// share a CU -- one streams its epilogue to HBM (per-CU store rate ~25 GB/s, ~30 us per tile) while the other computes.
+// TPW = tile rows per wave: 8 (wave tile 128 px x 64 couts, <= 256 VGPRs) or 4 (64 px x 64 couts, <= 128 VGPRs).
+// NW = weight ring depth.  Workgroup shapes (waves = WP x WC):
+//   <2,2,0,8,4>  4 waves x 256 VGPRs, 16x16 px x 128 couts, 80 KB LDS: TWO workgroups per CU -- the default for every
+//                plain-input layer: a tile spends ~12 us outside its main loop (index math, first-DMA latency, epilogue
+//                VALU + stores, statistics; tools/stamp_halo.py) and the other workgroup's MFMAs run under them;
+//   <4,2,0,4,4>  8 waves x 128 VGPRs, same tile, two workgroups per CU (the earlier form of the same idea);
+//   <2,4,.,8,6> / <4,2,.,8,6>  8 waves x 256 VGPRs, 256 / 128 couts, one workgroup per CU (and the only shapes of XT != 0).
 template <int WP, int WC, int XT, int TPW, int NW>
 __global__ __launch_bounds__(64 * WP * WC, TPW == 4 ? 4 : 2)
 void conv3x3_halo_kernel(const Conv3x3Args a) {
