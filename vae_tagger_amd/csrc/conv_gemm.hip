@@ -94,7 +94,10 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
 #pragma unroll
     for (int j = 0; j < NWJ; ++j) {
         const int rblk = j * 8 + wave;
-        const int n = c0 + rblk * 8 + lrow;
+        // 64-cout wave groups use the interleaved cout map of conv3x3_halo (LDS row 16*i + 4*q + r holds cout r + 4*i + 16*q):
+        // MFMA tile i / register r of lane (fq, frow) is then cout 16*fq + 4*i + r -- 16 consecutive couts per lane
+        const int rl = rblk * 8 + lrow;
+        const int n = c0 + (TC == 4 ? (rl & ~63) + (rl & 3) + 4 * ((rl >> 4) & 3) + 16 * ((rl >> 2) & 3) : rl);
         wvalid[j] = (rblk < WI) && (n < a.Wrows);
         woff[j] = n * a.ldw + lchunk * 8;
     }
@@ -168,19 +171,22 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
         }
     }
 
-    // ---- epilogue: lane holds couts cg..cg+3 (regs) of pixel p for every (i, j) tile.
+    // ---- epilogue: lane holds couts cg(i)..+3 (regs) of pixel p for every (i, j) tile; with the interleaved map (TC == 4)
+    // the four tiles of a row are 16 consecutive couts -> two 16-B stores of 16-bit outputs per row instead of four 8-B ones.
     const long long ob = (long long)b * a.o_bs;
     const float* resb = a.res ? a.res + (long long)b * a.r_bs : nullptr;
     const f16_t* resh = a.res_f16 ? a.res_f16 + (long long)b * a.r_bs : nullptr;
+    const bool wide16 = TC == 4 && (a.ldo % 8) == 0 && (a.o_bs % 8) == 0;
     unsigned valid = 0;
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int p = p0 + wp * (BP / WP) + j * 16 + frow;
         if (p >= HWo) continue;
         valid |= 1u << j;
+        const int cg0 = c0 + wc * (BC / WC) + (TC == 4 ? fq * 16 : fq * 4);
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
-            const int cg = c0 + wc * (BC / WC) + i * 16 + fq * 4;
+            const int cg = cg0 + (TC == 4 ? i * 4 : i * 16);
             if (cg >= a.Cout) continue;
             f32x4 v = acc[i][j] * a.alpha;
             if (a.bias_mode == 1) {
@@ -207,17 +213,40 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
                 v += f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
             }
             if (a.out_f32) *(f32x4*)(a.out_f32 + ob + o) = v;
-            if (a.out_bf16) {
-                bf16x4 h;
-                h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
-                *(bf16x4*)(a.out_bf16 + ob + o) = h;
-            }
-            if (a.out_f16) {
-                f16x4 h;
-                h[0] = (f16_t)v[0]; h[1] = (f16_t)v[1]; h[2] = (f16_t)v[2]; h[3] = (f16_t)v[3];
-                *(f16x4*)(a.out_f16 + ob + o) = h;
+            if (!(wide16 && cg0 + 16 <= a.Cout)) {
+                if (a.out_bf16) {
+                    bf16x4 h;
+                    h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
+                    *(bf16x4*)(a.out_bf16 + ob + o) = h;
+                }
+                if (a.out_f16) {
+                    f16x4 h;
+                    h[0] = (f16_t)v[0]; h[1] = (f16_t)v[1]; h[2] = (f16_t)v[2]; h[3] = (f16_t)v[3];
+                    *(f16x4*)(a.out_f16 + ob + o) = h;
+                }
             }
             acc[i][j] = v;
+        }
+        if constexpr (TC == 4) {
+            if (wide16 && cg0 + 16 <= a.Cout && a.out_mode == 0) {
+                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                const long long o = ob + (long long)p * a.ldo + cg0;
+#pragma unroll
+                for (int i = 0; i < TC; i += 2) {
+                    if (a.out_bf16) {
+                        bf16x8 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { h[r] = (bf16_t)acc[i][j][r]; h[4 + r] = (bf16_t)acc[i + 1][j][r]; }
+                        *(bf16x8*)(a.out_bf16 + o + 4 * i) = h;
+                    }
+                    if (a.out_f16) {
+                        f16x8 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { h[r] = (f16_t)acc[i][j][r]; h[4 + r] = (f16_t)acc[i + 1][j][r]; }
+                        *(f16x8*)(a.out_f16 + o + 4 * i) = h;
+                    }
+                }
+            }
         }
     }
     if (a.gn_partial) {
@@ -225,7 +254,8 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
         __syncthreads();
         const int G = a.Cout / a.gn_cpg;
         float* out = a.gn_partial + (((long long)b * ptiles + (p0 / BP)) * G + c0 / a.gn_cpg) * 3;
-        vt_gn_epilogue_partials<TC, TP>(acc, valid, a.gn_cpg, wp, WP, wc * (BC / WC), BC, (float*)smem, out);
+        if constexpr (TC == 4) vt_gn_epilogue_partials_il<TC, TP>(acc, valid, a.gn_cpg, wp, WP, wc * (BC / WC), BC, (float*)smem, out);
+        else vt_gn_epilogue_partials<TC, TP>(acc, valid, a.gn_cpg, wp, WP, wc * (BC / WC), BC, (float*)smem, out);
     }
 }
 
