@@ -241,14 +241,10 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
     if (gn_partial) {
         // 32 GroupNorm groups of 4 couts: group of (half h, fq, tile i) = 16*h + 4*fq + i.  Sums are relative to the
         // group's first bias (E[x] ~ 0 makes that a good pivot); merge the 16 pixel columns, then the 4 waves.
-        float n = 4.0f * (float)cnt;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) n += __shfl_xor(n, o, 64);
+        const float n = vt_row16_sum(4.0f * (float)cnt);              // 16-lane DPP row sums (vt_common.h)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float s1 = gs[i], s2 = gss[i];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            const float s1 = vt_row16_sum(gs[i]), s2 = vt_row16_sum(gss[i]);
             if (fr == 0) {
                 const int g = 16 * (i >> 2) + 4 * fq + (i & 3);
                 const float ms = n > 0.f ? s1 / n : 0.f;
