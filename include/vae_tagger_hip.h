@@ -79,6 +79,18 @@ int vt_encode_tag(vt_context* ctx, const float* x_nchw, int B, int H, int W, flo
  * uint8 HWC RGB [B,H,W,3] -> fp32 NCHW [B,3,H,W] in [-1,1] (the resize stays with PIL on the host). */
 int vt_preprocess_u8(vt_context* ctx, const uint8_t* in_hwc, int B, int H, int W, float* out_nchw, void* stream);
 
+/* vt_resize_u8 <- transforms.Resize((r, r)) (filter 0, bilinear) and SmartResize's crop + Image.resize(LANCZOS) (filter 1),
+ * modules.py:126-178: Pillow's two-pass 8-bit resample (libImaging/Resample.c) reproduced bit for bit on the device.
+ * src: uint8 HWC RGB [src_h][src_w][3]; the crop box (left, top, crop_w, crop_h) inside it is resized to dst uint8 HWC
+ * [dst_h][dst_w][3].  The coefficient tables are built on the host exactly as Pillow builds them and copied with the
+ * stream; the call does not wait for the GPU (it may wait for the PREVIOUS call's table copy). */
+size_t vt_resize_workspace_bytes(int crop_h, int crop_w, int dst_h, int dst_w, int filter);
+/* Host-only: one axis' table as vt_resize_u8 builds it, table_out[out_size][2 + ksize] = (first sample, count,
+ * 22-bit coefficients...); returns ksize (call with table_out = NULL to size the buffer), -1 on a bad argument. */
+int vt_resize_table(int in_size, int out_size, int filter, int* table_out, int table_ints);
+int vt_resize_u8(vt_context* ctx, const uint8_t* src_hwc, int src_h, int src_w, int crop_left, int crop_top, int crop_w, int crop_h,
+                 uint8_t* dst_hwc, int dst_h, int dst_w, int filter, void* workspace, size_t workspace_bytes, void* stream);
+
 /* algorithmic FLOPs of one encoder forward at HxW -- for roofline reporting */
 double vt_encoder_flops(const vt_context* ctx, int H, int W);
 

@@ -19,7 +19,7 @@ def _flags(parser):
 
 def test_cli_flags_match_reference():
     assert REF_FULL_FLAGS <= _flags(infer_full.build_parser())
-    assert _flags(infer_full.build_parser()) - REF_FULL_FLAGS == {"--batch_size"}
+    assert _flags(infer_full.build_parser()) - REF_FULL_FLAGS == {"--batch_size", "--device_resize"}
     assert _flags(infer_vae.build_parser()) - REF_VAE_FLAGS == {"--batch_size"}
     a = infer_full.build_parser().parse_args(["--vae_checkpoint", "v", "--decoder_checkpoint", "d", "--image_path", "i",
                                               "--tags_csv_path", "t"])
@@ -67,6 +67,12 @@ def test_infer_full_and_infer_vae_end_to_end(tmp_path):
                                 "--confidence_threshold", "0.5", "--batch_size", "2"])
     written = json.loads((out / "classification_results.json").read_text())
     assert written == res_full and len(written) == 3
+    # the same run with resize + normalise on the GPU: Pillow's arithmetic reproduced exactly -> the identical JSON
+    res_dev = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint",
+                               str(tmp_path / "dec.pth"), "--image_path", str(imgs), "--tags_csv_path",
+                               str(tmp_path / "tags.csv"), "--output_dir", str(tmp_path / "out_dev"), "--resolution", str(res),
+                               "--confidence_threshold", "0.5", "--batch_size", "2", "--device_resize"])
+    assert res_dev == res_full
     lat = infer_vae.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--image_path", str(imgs),
                           "--output_dir", str(out), "--resolution", str(res)])
     assert len(lat) == 3 and all(len(v) == 16 * (res // 8) ** 2 for v in lat.values())

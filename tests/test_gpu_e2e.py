@@ -219,3 +219,30 @@ def test_evaluation_caller_matches_oracle(vae, tmp_path):
     assert (tmp_path / "evaluation_results.csv").read_text().splitlines()[0] == "class_name,precision,recall,f1,ap,support"
     r = find_optimal_threshold(vae, dec, batches, names, device="cuda", output_dir=str(tmp_path))
     assert 0.1 <= r["global_threshold"] < 0.9 and set(r["per_class_thresholds"]) == set(names)
+
+
+def test_device_resize_is_bit_exact_with_pillow(vae):
+    """vt_resize_u8 / EncodeTagPipeline.load_image against Pillow itself (the library the reference's transforms call,
+    modules.py:126-178): uint8 results identical, and the normalised fp32 tensor identical to ToTensor + Normalize."""
+    import numpy as np
+    from PIL import Image
+    from oracle import resize_ref
+    from vae_tagger_amd.modules import get_image_transform
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+    pipe = EncodeTagPipeline(vae, _decoder(11))
+    rng = np.random.default_rng(3)
+    for (h, w, ow, oh) in [(37, 53, 16, 16), (480, 640, 256, 256), (1333, 2000, 1024, 1024), (100, 90, 256, 320), (64, 64, 64, 200),
+                           (200, 64, 64, 64), (50, 50, 50, 50)]:
+        a = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        for filt, pk in ((pipe.FILTER_BILINEAR, Image.BILINEAR), (pipe.FILTER_LANCZOS, Image.LANCZOS)):
+            want = np.asarray(Image.fromarray(a).resize((ow, oh), pk))
+            got = pipe.resize_u8(a, ow, oh, filt).cpu().numpy()
+            assert np.array_equal(got, want), (h, w, ow, oh, filt, int(np.abs(got.astype(int) - want.astype(int)).max()))
+    # crop box + the two transforms of get_image_transform, through load_image
+    a = rng.integers(0, 256, (300, 500, 3)).astype(np.uint8)
+    img = Image.fromarray(a)
+    box = resize_ref.smart_crop_box(500, 300, 192, 256)
+    want = np.asarray(img.crop((box[0], box[1], box[0] + box[2], box[1] + box[3])).resize((192, 256), Image.LANCZOS))
+    assert np.array_equal(pipe.resize_u8(a, 192, 256, pipe.FILTER_LANCZOS, box).cpu().numpy(), want)
+    for kw, ref_t in (({"resolution": 128}, get_image_transform(128)), ({"bucket": (192, 256)}, get_image_transform(0, True, (192, 256)))):
+        assert torch.equal(pipe.load_image(img, **kw).cpu(), ref_t(img))

@@ -153,3 +153,24 @@ def test_evaluation_metrics_match_scikit_learn():
     assert m2["per_class"]["t0"] == {"precision": 0.0, "recall": 0.0, "f1": 0.0, "ap": 0.0, "support": 0}
     assert m2["per_class"]["t1"]["ap"] == 1.0 and m2["per_class"]["t1"]["recall"] == 1.0
     assert m2["mAP"] == 0.0                                  # scikit-learn raises / warns here; the reference reports 0
+
+
+def test_resize_tables_match_the_oracle():
+    """vt_resize_table (host code of the C ABI) builds Pillow's per-axis tables; the numpy oracle (pinned against Pillow in
+    tests/test_oracle.py) is the checker.  No GPU involved."""
+    import ctypes
+    import numpy as np
+    from oracle import resize_ref as R
+    from vae_tagger_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    cases = [(4000, 1024, 1), (3000, 1024, 0), (300, 1024, 1), (1024, 1024, 0), (7, 3, 1), (1, 5, 0)]
+    cases += [(int(rng.integers(1, 2500)), int(rng.integers(1, 1100)), int(rng.integers(0, 2))) for _ in range(30)]
+    for n_in, n_out, kind in cases:
+        ks = lib.vt_resize_table(n_in, n_out, kind, None, 0)
+        buf = (ctypes.c_int * (n_out * (2 + ks)))()
+        assert lib.vt_resize_table(n_in, n_out, kind, buf, len(buf)) == ks
+        tab = np.frombuffer(buf, dtype=np.int32).reshape(n_out, 2 + ks)
+        bounds, kk = R.coefficients(n_in, n_out, kind)
+        assert kk.shape[1] == ks and np.array_equal(tab[:, :2], bounds) and np.array_equal(tab[:, 2:], kk), (n_in, n_out, kind)
+    assert lib.vt_resize_table(0, 5, 0, None, 0) == -1 and lib.vt_resize_table(5, 5, 2, None, 0) == -1

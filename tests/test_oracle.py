@@ -80,3 +80,23 @@ def test_encoder_restatement_matches_committed_latents(name, h, w):
 def test_encoder_flops_match_survey():
     assert abs(encoder_ref.encoder_flops(1024, 1024) / 1e12 - 4.8826) < 2e-3
     assert abs(encoder_ref.encoder_flops(512, 512) / 1e12 - 1.1176) < 2e-3
+
+
+def test_resize_restatement_matches_pillow_bit_for_bit():
+    """oracle/resize_ref.py restates Pillow's ImagingResample (what transforms.Resize / SmartResize end up calling,
+    modules.py:126-178); Pillow itself is installed here and pins it: random images, up- and down-scaling, both filters."""
+    import numpy as np
+    from PIL import Image
+    from oracle import resize_ref as R
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        h, w = int(rng.integers(5, 160)), int(rng.integers(5, 160))
+        oh, ow = int(rng.integers(4, 120)), int(rng.integers(4, 120))
+        a = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        for kind, pk in ((R.BILINEAR, Image.BILINEAR), (R.LANCZOS, Image.LANCZOS)):
+            want = np.asarray(Image.fromarray(a).resize((ow, oh), pk))
+            assert np.array_equal(R.resize(a, ow, oh, kind), want), (h, w, oh, ow, kind)
+    # SmartResize's crop box (centre mode) against the arithmetic at modules.py:150-175
+    assert R.smart_crop_box(400, 200, 512, 512) == (100, 0, 200, 200)
+    assert R.smart_crop_box(200, 400, 512, 512) == (0, 100, 200, 200)
+    assert R.smart_crop_box(300, 300, 640, 640) == (0, 0, 300, 300)

@@ -34,6 +34,9 @@ PROTOTYPES = {
     "vt_encode_tag_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "vt_encode_tag": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vt_preprocess_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "vt_resize_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "vt_resize_table": (_i, [_i, _i, _i, _c.POINTER(_i), _i]),
+    "vt_resize_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "vt_encoder_flops": (_c.c_double, [_vp, _i, _i]),
     "vt_set_flag": (_i, [_vp, _i, _i]),
     "vt_profile_num_configs": (_i, []),

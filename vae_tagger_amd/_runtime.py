@@ -81,9 +81,9 @@ class HipModule(ParamTree):
 _workspaces = {}
 
 
-def workspace(device, nbytes):
-    """Grow-only per-device scratch tensor (caller-owned buffer of the C ABI)."""
-    key = (device.type, device.index)
+def workspace(device, nbytes, tag=""):
+    """Grow-only per-device scratch tensor (caller-owned buffer of the C ABI); `tag` names an independent buffer."""
+    key = (device.type, device.index, tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         _workspaces[key] = None

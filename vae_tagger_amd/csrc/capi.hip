@@ -81,6 +81,8 @@ struct vt_context {
     int fuse_gn_stats = 1;          // vt_set_flag(ctx, 1, v)
     int fuse_gn_apply = 0;          // vt_set_flag(ctx, 2, v): break-even on MI355X today, off by default
     int res_fp16 = 1;               // vt_set_flag(ctx, 4, v): residual stream stored as fp16 (math stays fp32)
+    // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
+    int* rs_host = nullptr; size_t rs_host_ints = 0; hipEvent_t rs_event = nullptr;
     int conv_in_mfma = 1;           // vt_set_flag(ctx, 5, v): conv_in on the matrix cores (bf16 im2col), else exact fp32 VALU
     void* op_scratch = nullptr; size_t op_scratch_bytes = 0;
 
@@ -456,6 +458,8 @@ void vt_destroy(vt_context* c) {
     (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->op_scratch) (void)hipFree(c->op_scratch);
+    if (c->rs_host) (void)hipHostFree(c->rs_host);
+    if (c->rs_event) (void)hipEventDestroy(c->rs_event);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->zeros) (void)hipFree(c->zeros);
     delete c;
@@ -876,6 +880,112 @@ int vt_profile_num_configs(void) { return VT_NUM_PROF_SLOTS; }
 int vt_preprocess_u8(vt_context* c, const uint8_t* in_hwc, int B, int H, int W, float* out_nchw, void* stream) {
     if (!c) return VT_ERR_INVALID;
     HIPCK(c, vt_launch_preprocess_u8(in_hwc, out_nchw, B, H, W, (hipStream_t)stream), "vt_preprocess_u8");
+    return VT_OK;
+}
+
+// ---- device-side resize (Pillow's ImagingResample, 8 bits per channel) ---------------------------
+namespace {
+constexpr int RS_BITS = 32 - 8 - 2;
+double rs_filter(int kind, double x) {
+    if (kind == 0) {                                   // bilinear_filter, support 1
+        if (x < 0.0) x = -x;
+        return x < 1.0 ? 1.0 - x : 0.0;
+    }
+    if (-3.0 <= x && x < 3.0) {                        // lanczos_filter, support 3 (truncated sinc)
+        auto sinc = [](double v) { if (v == 0.0) return 1.0; v *= M_PI; return sin(v) / v; };
+        return sinc(x) * sinc(x / 3);
+    }
+    return 0.0;
+}
+int rs_ksize(int in_size, int out_size, int kind) {
+    double fs = (double)in_size / out_size;
+    if (fs < 1.0) fs = 1.0;
+    return (int)ceil((kind == 0 ? 1.0 : 3.0) * fs) * 2 + 1;
+}
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc for box (0, in_size): tab[xx] = (first, count, coefficients[ksize])
+void rs_table(int in_size, int out_size, int kind, int* tab) {
+    const double scale = (double)in_size / out_size;
+    double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = (kind == 0 ? 1.0 : 3.0) * filterscale, ss = 1.0 / filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    std::vector<double> w(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) { w[x] = rs_filter(kind, (x + xmin - center + 0.5) * ss); ww += w[x]; }
+        int* t = tab + (size_t)xx * (2 + ksize);
+        t[0] = xmin; t[1] = xmax;
+        for (int x = 0; x < ksize; ++x) {
+            double v = x < xmax ? w[x] : 0.0;
+            if (x < xmax && ww != 0.0) v /= ww;
+            t[2 + x] = v < 0 ? (int)(-0.5 + v * (1 << RS_BITS)) : (int)(0.5 + v * (1 << RS_BITS));
+        }
+    }
+}
+struct RsPlan { int kh, kv; size_t tab_h, tab_v, tmp, total; };   // table sizes in ints, tmp / total in bytes
+RsPlan rs_plan(int crop_h, int crop_w, int dst_h, int dst_w, int kind) {
+    RsPlan p{};
+    const bool nh = dst_w != crop_w, nv = dst_h != crop_h;
+    p.kh = nh ? rs_ksize(crop_w, dst_w, kind) : 0;
+    p.kv = nv ? rs_ksize(crop_h, dst_h, kind) : 0;
+    p.tab_h = nh ? (size_t)dst_w * (2 + p.kh) : 0;
+    p.tab_v = nv ? (size_t)dst_h * (2 + p.kv) : 0;
+    p.tmp = (nh && nv) ? (size_t)crop_h * dst_w * 3 : ((nv && !nh) ? (size_t)crop_h * crop_w * 3 : 0);
+    p.total = align_up((p.tab_h + p.tab_v) * 4) + align_up(p.tmp);
+    return p;
+}
+}  // namespace
+
+int vt_resize_table(int in_size, int out_size, int filter, int* table_out, int table_ints) {
+    if (in_size <= 0 || out_size <= 0 || (filter != 0 && filter != 1)) return -1;
+    const int ks = rs_ksize(in_size, out_size, filter);
+    if (!table_out) return ks;
+    if ((long long)table_ints < (long long)out_size * (2 + ks)) return -1;
+    rs_table(in_size, out_size, filter, table_out);
+    return ks;
+}
+
+size_t vt_resize_workspace_bytes(int crop_h, int crop_w, int dst_h, int dst_w, int filter) {
+    if (crop_h <= 0 || crop_w <= 0 || dst_h <= 0 || dst_w <= 0 || (filter != 0 && filter != 1)) return 0;
+    return rs_plan(crop_h, crop_w, dst_h, dst_w, filter).total + 256;
+}
+
+int vt_resize_u8(vt_context* c, const uint8_t* src_hwc, int src_h, int src_w, int crop_left, int crop_top, int crop_w, int crop_h,
+                 uint8_t* dst_hwc, int dst_h, int dst_w, int filter, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c) return VT_ERR_INVALID;
+    if (!src_hwc || !dst_hwc || (filter != 0 && filter != 1) || crop_w <= 0 || crop_h <= 0 || dst_w <= 0 || dst_h <= 0 ||
+        crop_left < 0 || crop_top < 0 || crop_left + crop_w > src_w || crop_top + crop_h > src_h)
+        return c->fail(VT_ERR_INVALID, "vt_resize_u8: bad argument");
+    HIPCK(c, hipSetDevice(c->device), "hipSetDevice");
+    const RsPlan p = rs_plan(crop_h, crop_w, dst_h, dst_w, filter);
+    char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (p.total && (!workspace || workspace_bytes < p.total + (size_t)(ws - (char*)workspace)))
+        return c->fail(VT_ERR_WORKSPACE, "vt_resize_u8: workspace %zu < required %zu", workspace_bytes, p.total + 256);
+    hipStream_t s = (hipStream_t)stream;
+    int* tab = (int*)ws;
+    const size_t ints = p.tab_h + p.tab_v;
+    if (ints) {
+        if (!c->rs_event) HIPCK(c, hipEventCreateWithFlags(&c->rs_event, hipEventDisableTiming), "hipEventCreate");
+        else HIPCK(c, hipEventSynchronize(c->rs_event), "hipEventSynchronize");     // the previous copy has read the staging buffer
+        if (c->rs_host_ints < ints) {
+            if (c->rs_host) (void)hipHostFree(c->rs_host);
+            c->rs_host = nullptr; c->rs_host_ints = 0;
+            HIPCK(c, hipHostMalloc((void**)&c->rs_host, ints * 4, hipHostMallocDefault), "hipHostMalloc");
+            c->rs_host_ints = ints;
+        }
+        if (p.tab_h) rs_table(crop_w, dst_w, filter, c->rs_host);
+        if (p.tab_v) rs_table(crop_h, dst_h, filter, c->rs_host + p.tab_h);
+        HIPCK(c, hipMemcpyAsync(tab, c->rs_host, ints * 4, hipMemcpyHostToDevice, s), "hipMemcpyAsync(tables)");
+        HIPCK(c, hipEventRecord(c->rs_event, s), "hipEventRecord");
+    }
+    unsigned char* tmp = p.tmp ? (unsigned char*)(ws + align_up(ints * 4)) : nullptr;
+    HIPCK(c, vt_launch_resize_u8(src_hwc, src_h, src_w, crop_left, crop_top, crop_w, crop_h, dst_hwc, dst_h, dst_w,
+                                 p.tab_h ? tab : nullptr, p.kh, p.tab_v ? tab + p.tab_h : nullptr, p.kv, tmp, s), "vt_resize_u8");
     return VT_OK;
 }
 

@@ -359,12 +359,90 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char*
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pillow's 8-bit two-pass resample (libImaging/Resample.c) on the device: the resize the reference runs on the CPU before
+// the encoder (modules.py:126-178).  The host builds Pillow's per-axis tables (first sample, count, 22-bit fixed-point
+// coefficients); these kernels apply them exactly as ImagingResampleHorizontal_8bpc / Vertical_8bpc do: int32
+// accumulation from a rounding half, arithmetic shift, clip to uint8, and the horizontal pass's uint8 feeds the vertical.
+// tab: [n_out][2 + ksize] int32 = (first, count, coefficients...).  3 channels, HWC.
+constexpr int RS_PRECISION_BITS = 32 - 8 - 2;
+__device__ __forceinline__ unsigned char rs_clip8(int v) {
+    v >>= RS_PRECISION_BITS;
+    return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+// src rows [top, top+rows) x cols [left, ...) of a [src_h][src_w][3] image -> out [rows][out_w][3]
+__global__ __launch_bounds__(256) void resize_h_kernel(const unsigned char* __restrict__ src, int src_w, int left, int top,
+                                                       const int* __restrict__ tab, int ksize, unsigned char* __restrict__ out,
+                                                       int rows, int out_w) {
+    const int xx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (xx >= out_w || y >= rows) return;
+    const int* t = tab + (long long)xx * (2 + ksize);
+    const int x0 = t[0], n = t[1];
+    const unsigned char* p = src + ((long long)(top + y) * src_w + left + x0) * 3;
+    int a0 = 1 << (RS_PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    for (int k = 0; k < n; ++k) {
+        const int c = t[2 + k];
+        a0 += p[3 * k] * c; a1 += p[3 * k + 1] * c; a2 += p[3 * k + 2] * c;
+    }
+    unsigned char* o = out + ((long long)y * out_w + xx) * 3;
+    o[0] = rs_clip8(a0); o[1] = rs_clip8(a1); o[2] = rs_clip8(a2);
+}
+// in [in_rows][w][3] -> out [out_h][w][3]
+__global__ __launch_bounds__(256) void resize_v_kernel(const unsigned char* __restrict__ in, const int* __restrict__ tab, int ksize,
+                                                       unsigned char* __restrict__ out, int w, int out_h) {
+    const int xx = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y;
+    if (xx >= w || yy >= out_h) return;
+    const int* t = tab + (long long)yy * (2 + ksize);
+    const int y0 = t[0], n = t[1];
+    const unsigned char* p = in + ((long long)y0 * w + xx) * 3;
+    int a0 = 1 << (RS_PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    for (int k = 0; k < n; ++k) {
+        const int c = t[2 + k];
+        const unsigned char* q = p + (long long)k * w * 3;
+        a0 += q[0] * c; a1 += q[1] * c; a2 += q[2] * c;
+    }
+    unsigned char* o = out + ((long long)yy * w + xx) * 3;
+    o[0] = rs_clip8(a0); o[1] = rs_clip8(a1); o[2] = rs_clip8(a2);
+}
+// plain crop copy (a pass whose size does not change is skipped, as in Pillow)
+__global__ __launch_bounds__(256) void crop_copy_kernel(const unsigned char* __restrict__ src, int src_w, int left, int top,
+                                                        unsigned char* __restrict__ out, int rows, int w) {
+    const int i = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (i >= w * 3 || y >= rows) return;
+    out[(long long)y * w * 3 + i] = src[((long long)(top + y) * src_w + left) * 3 + i];
+}
+
 }  // namespace
 
 hipError_t vt_launch_preprocess_u8(const unsigned char* in_hwc, float* out_nchw, int B, int H, int W, hipStream_t s) {
     if (!in_hwc || !out_nchw || B <= 0 || H <= 0 || W <= 0) return hipErrorInvalidValue;
     const long long HW = (long long)H * W;
     hipLaunchKernelGGL(preprocess_u8_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, s, in_hwc, out_nchw, HW);
+    return hipGetLastError();
+}
+
+hipError_t vt_launch_resize_u8(const unsigned char* src, int src_h, int src_w, int left, int top, int crop_w, int crop_h,
+                               unsigned char* dst, int dst_h, int dst_w, const int* tab_h, int ksize_h, const int* tab_v,
+                               int ksize_v, unsigned char* tmp, hipStream_t s) {
+    if (!src || !dst || left < 0 || top < 0 || crop_w <= 0 || crop_h <= 0 || left + crop_w > src_w || top + crop_h > src_h ||
+        dst_h <= 0 || dst_w <= 0 || dst_h > 65535 || crop_h > 65535)
+        return hipErrorInvalidValue;
+    const bool need_h = dst_w != crop_w, need_v = dst_h != crop_h;
+    if ((need_h && !tab_h) || (need_v && !tab_v) || (need_h && need_v && !tmp)) return hipErrorInvalidValue;
+    if (!need_h && !need_v) {
+        hipLaunchKernelGGL(crop_copy_kernel, dim3((crop_w * 3 + 255) / 256, crop_h), dim3(256), 0, s, src, src_w, left, top, dst, crop_h, crop_w);
+        return hipGetLastError();
+    }
+    if (need_h) {
+        unsigned char* o = need_v ? tmp : dst;
+        hipLaunchKernelGGL(resize_h_kernel, dim3((dst_w + 255) / 256, crop_h), dim3(256), 0, s, src, src_w, left, top, tab_h, ksize_h, o, crop_h, dst_w);
+        if (need_v) hipLaunchKernelGGL(resize_v_kernel, dim3((dst_w + 255) / 256, dst_h), dim3(256), 0, s, tmp, tab_v, ksize_v, dst, dst_w, dst_h);
+    } else {
+        // vertical only: the source rows are the crop itself; copy it out first so the pass reads a dense [crop_h][w][3] image
+        if (!tmp) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(crop_copy_kernel, dim3((crop_w * 3 + 255) / 256, crop_h), dim3(256), 0, s, src, src_w, left, top, tmp, crop_h, crop_w);
+        hipLaunchKernelGGL(resize_v_kernel, dim3((dst_w + 255) / 256, dst_h), dim3(256), 0, s, tmp, tab_v, ksize_v, dst, dst_w, dst_h);
+    }
     return hipGetLastError();
 }
 

@@ -90,6 +90,11 @@ hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shi
                               int C, int silu, hipStream_t s);
 
 hipError_t vt_launch_preprocess_u8(const unsigned char* in_hwc, float* out_nchw, int B, int H, int W, hipStream_t s);
+// Pillow's two-pass 8-bit resample; tab_*: [n_out][2 + ksize] int32 (first, count, 22-bit coefficients) on the device;
+// tmp: crop_h * dst_w * 3 bytes (or crop_h * crop_w * 3 when only the height changes)
+hipError_t vt_launch_resize_u8(const unsigned char* src, int src_h, int src_w, int left, int top, int crop_w, int crop_h,
+                               unsigned char* dst, int dst_h, int dst_w, const int* tab_h, int ksize_h, const int* tab_v,
+                               int ksize_v, unsigned char* tmp, hipStream_t s);
 
 // row softmax: scores fp32 or fp16 [rows][lds] -> probs bf16 [rows][ldp]; columns [n, ldp) are written as zero.
 hipError_t vt_launch_softmax_rows(const void* scores, int scores_f16, bf16_t* probs, long long rows, int n, int lds,

@@ -109,7 +109,9 @@ def infer_and_classify(args):
         batch, names = [], []
         for p in image_paths[start:start + bs]:
             try:
-                batch.append(transform(Image.open(p).convert("RGB")))
+                img = Image.open(p).convert("RGB")
+                batch.append(pipe.load_image(img, resolution=args.resolution) if getattr(args, "device_resize", False)
+                             else transform(img))
                 names.append(p)
             except Exception as e:  # noqa: BLE001 - skip-and-count (infer_full.py:130-132)
                 errors += 1
@@ -156,6 +158,8 @@ def build_parser():
     p.add_argument("--attention_dropout", type=float, default=0.1, help="注意力dropout率")
     p.add_argument("--model_checkpoint", type=str, default=None, help="(已弃用) 包含VAE和Decoder权重的父目录")
     p.add_argument("--batch_size", type=int, default=8, help="images per device batch (not in the reference)")
+    p.add_argument("--device_resize", action="store_true",
+                   help="resize + normalise on the GPU (bit-exact with the PIL transform; not in the reference)")
     return p
 
 

@@ -74,5 +74,49 @@ class EncodeTagPipeline:
         self.ctx.call("vt_preprocess_u8", vp(u8), B, H, W, vp(out), stream_ptr(self.device))
         return out
 
+    # ---- device-side resize: the reference's PIL transforms (modules.py:126-178) reproduced bit for bit on the GPU ----
+    FILTER_BILINEAR, FILTER_LANCZOS = 0, 1
+
+    @torch.no_grad()
+    def resize_u8(self, u8_hwc, out_w, out_h, filt, box=None):
+        """uint8 [H,W,3] (tensor or array) -> uint8 [out_h,out_w,3] on the device = Image.resize((out_w, out_h), filt)
+        of the image cropped to box = (left, top, width, height); Pillow's 8-bit two-pass resample, exactly."""
+        t = torch.as_tensor(u8_hwc)
+        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[-1] != 3:
+            raise ValueError(f"expected uint8 [H,W,3], got {t.dtype} {tuple(t.shape)}")
+        t = t.to(self.device).contiguous()
+        H, W, _ = t.shape
+        left, top, cw, ch = box if box is not None else (0, 0, W, H)
+        out = torch.empty(out_h, out_w, 3, dtype=torch.uint8, device=self.device)
+        need = self.ctx.lib.vt_resize_workspace_bytes(ch, cw, out_h, out_w, filt)
+        if need == 0:
+            raise _lib.VTError(f"unsupported resize {cw}x{ch} -> {out_w}x{out_h}")
+        ws, ptr = workspace(self.device, need, "resize")
+        self.ctx.call("vt_resize_u8", vp(t), H, W, left, top, cw, ch, vp(out), out_h, out_w, filt, ctypes.c_void_p(ptr), need,
+                      stream_ptr(self.device))
+        return out
+
+    def load_image(self, img, resolution=None, bucket=None):
+        """Device counterpart of `get_image_transform(resolution, bucket is not None, bucket)(img)`: a PIL image (or a
+        uint8 HWC array) -> fp32 [3,H,W] in [-1,1] on the device.  Only the decoded uint8 pixels cross PCIe; the
+        distorting bilinear `Resize((r, r))` or SmartResize's centre crop + LANCZOS run on the GPU with Pillow's arithmetic."""
+        import numpy as np
+        a = np.asarray(img.convert("RGB") if hasattr(img, "convert") else img, dtype=np.uint8)
+        H, W, _ = a.shape
+        if bucket is not None:
+            tw, th = bucket
+            ratio, target = W / H, tw / th
+            box = (0, 0, W, H)
+            if ratio > target:
+                nw = int(H * target)
+                box = ((W - nw) // 2, 0, nw, H)
+            elif ratio < target:
+                nh = int(W / target)
+                box = (0, (H - nh) // 2, W, nh)
+            u8 = self.resize_u8(torch.from_numpy(a.copy()), tw, th, self.FILTER_LANCZOS, box)
+        else:
+            u8 = self.resize_u8(torch.from_numpy(a.copy()), resolution, resolution, self.FILTER_BILINEAR)
+        return self.normalize_u8(u8[None])[0]
+
     def tag(self, x):
         return self.confidence(self.logits(x))
