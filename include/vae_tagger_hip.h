@@ -109,7 +109,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  * flag 5: 1 (default) = conv_in (3 -> 128 channels) runs on the matrix cores from a bf16 im2col operand,
  *         0 = exact fp32 VALU conv.
  * flag 6: 1 (default) = 1x1 / GEMM launches with K <= 512 and no statistics epilogue (resnet shortcuts, attention
- *         projections, Q.K^T) use a 192x128 tile at two workgroups per CU, 0 = the 256x256 tile (process-wide).
+ *         projections, Q.K^T) and the 128-cout stride-2 conv use a 192x128 tile at two workgroups per CU,
+ *         0 = the 256x256 / 256x128 tiles (process-wide).
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 
