@@ -131,27 +131,21 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 // conv_in on the matrix cores (Cout == 128): the 27 taps x channels of each pixel become one K = 32 operand row
 // (im2col built in LDS from the fp32 halo, rounded to bf16), so the whole conv is ONE v_mfma_f32_16x16x32_bf16
 // K-step per 16x16 output tile; the kernel is then bound by its output write.  Workgroup = 4 waves, 8 rows x 64
-// pixels x 128 couts; LDS: fp32 halo 3 x 10 x 66, X rows 512 x 64 B, W rows 128 x 64 B (64-B-row swizzle as in
-// conv3x3_halo).  Weight rows use the interleaved cout map: lane (fq, fr) holds couts 64*h + 16*fq + 4*i + r
+// pixels x 128 couts; LDS: fp32 halo 3 x 10 x 66 (reused for the statistics), X rows 512 x 64 B (64-B-row swizzle as in
+// conv3x3_halo) = 40 KB, four workgroups per CU; the 8 KB of weights go straight from L2 to registers.  Weight rows use the interleaved cout map: lane (fq, fr) holds couts 64*h + 16*fq + 4*i + r
 // of pixel fr (tile i of half h), i.e. 16 consecutive couts per half -> 32-B fp16 / 64-B fp32 stores.
 // wpk: [128 rows][32 k] bf16 in that row order, k = ci*9 + ky*3 + kx, k >= 27 zero.
 constexpr int CM_ROWS = 8, CM_PIX = 64;
-__global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wpk,
+__global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ o32,
                                                            bf16_t* __restrict__ o16, f16_t* __restrict__ oh,
                                                            float* __restrict__ gn_partial, int H, int W) {
     constexpr int RW = CM_PIX + 2, RH = CM_ROWS + 2, NPX = CM_ROWS * CM_PIX, C = 128;
     __shared__ __attribute__((aligned(16))) float sin[3 * RH * RW];
     __shared__ __attribute__((aligned(16))) char xs[NPX * 64];
-    __shared__ __attribute__((aligned(16))) char ws[C * 64];
-    __shared__ float red[4][32][3];
+    float (*red)[32][3] = (float (*)[32][3])sin;       // statistics scratch: reuses the halo once the im2col is built
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, y0 = blockIdx.y * CM_ROWS, x0 = blockIdx.x * CM_PIX;
-    // weights: 8 KB, 16 B per thread x 2, swizzled like every 64-B-row LDS image here
-    for (int i = tid; i < C * 4; i += 256) {
-        const int row = i >> 2, ch = i & 3;
-        *(bf16x8*)(ws + row * 64 + ((ch ^ (((row >> 2) & 1) << 1)) << 4)) = *(const bf16x8*)(wpk + row * 32 + ch * 8);
-    }
     for (int i = tid; i < 3 * RH * RW; i += 256) {
         const int c = i / (RH * RW), r = (i / RW) % RH, xx = i % RW;
         const int iy = y0 - 1 + r, ix = x0 - 1 + xx;
@@ -185,8 +179,7 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
     bf16x8 wf[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int row = i * 16 + fr;
-        wf[i] = *(const bf16x8*)(ws + row * 64 + ((fq ^ (((row >> 2) & 1) << 1)) << 4));
+        wf[i] = *(const bf16x8*)(wpk + (i * 16 + fr) * 32 + fq * 8);   // 8 KB of weights, L2-resident: straight to registers
     }
     f32x4 bv[8];
 #pragma unroll
@@ -195,42 +188,74 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 8; ++i) gs[i] = gss[i] = 0.f;
     int cnt = 0;
-    // wave w: tile rows 2w, 2w+1 (128 pixels = 8 pixel tiles)
-#pragma unroll 2
+    // wave w: tile rows 2w, 2w+1 (128 pixels = 8 pixel tiles).  In the accumulator layout neighbouring lanes are
+    // neighbouring PIXELS (256 B apart in the 16-bit output), so 16-bit outputs are transposed through LDS -- the wave's own,
+    // already consumed, 8 KB of im2col rows -- and leave as 1 KB contiguous per store (4 pixels x 128 channels).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    // Staging area = the first 4 KB of the wave's own 8 KB of im2col rows, i.e. the rows of pixel tiles 0..3, free once
+    // their fragments are in registers; the fragments are read four tiles at a time.  Staged rows are 256 B (128 couts x 2 B)
+    // with the 16-B chunk index XOR-ed with the pixel (accumulator-layout writes touch 16 rows per access).
+    char* const stg = xs + wave * (128 * 64);
+    bf16x8 xfa[4];
+#pragma unroll 4
     for (int t = 0; t < 8; ++t) {
+        if ((t & 3) == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pu = wave * 128 + (t + u) * 16 + fr;
+                xfa[u] = *(const bf16x8*)(xs + pu * 64 + ((fq ^ (((pu >> 2) & 1) << 1)) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (before the staging below overwrites tiles 0..3)
+        }
+        const bf16x8 xft = (t & 3) == 0 ? xfa[0] : ((t & 3) == 1 ? xfa[1] : ((t & 3) == 2 ? xfa[2] : xfa[3]));
         const int p = wave * 128 + t * 16 + fr;                       // this lane's pixel in the tile
-        const bf16x8 xf = *(const bf16x8*)(xs + p * 64 + ((fq ^ (((p >> 2) & 1) << 1)) << 4));
         const int y = y0 + (p >> 6), xx = x0 + (p & 63);
         const bool ok = y < H && xx < W;
         const long long o = (((long long)b * H + y) * W + xx) * C + 16 * fq;
         f32x4 acc[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf, bv[i], 0, 0, 0);
-        if (ok) {
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xft, bv[i], 0, 0, 0);
+        if (ok && o32) {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const long long oo = o + 64 * hh;
-                if (o32) {
+            for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) *(f32x4*)(o32 + oo + 4 * i) = acc[hh * 4 + i];
-                }
+                for (int i = 0; i < 4; ++i) *(f32x4*)(o32 + o + 64 * hh + 4 * i) = acc[hh * 4 + i];
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            char* outp = pass == 0 ? (char*)oh : (char*)o16;
+            if (!outp) continue;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {
-                    if (oh) {
-                        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                    char* d = stg + fr * 256 + (((hh * 8 + fq * 2 + (i >> 1)) ^ fr) << 4);
+                    if (pass == 0) {
                         f16x8 h;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { h[r] = (f16_t)acc[hh * 4 + i][r]; h[4 + r] = (f16_t)acc[hh * 4 + i + 1][r]; }
-                        *(f16x8*)(oh + oo + 4 * i) = h;
-                    }
-                    if (o16) {
+                        *(f16x8*)d = h;
+                    } else {
                         bf16x8 h;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { h[r] = (bf16_t)acc[hh * 4 + i][r]; h[4 + r] = (bf16_t)acc[hh * 4 + i + 1][r]; }
-                        *(bf16x8*)(o16 + oo + 4 * i) = h;
+                        *(bf16x8*)d = h;
                     }
                 }
+            asm volatile("" ::: "memory");                              // (LDS executes one wave's accesses in order)
+            const int p0 = wave * 128 + t * 16;                        // the tile's first pixel: 16 consecutive x of one row
+            const int ty = y0 + (p0 >> 6), tx = x0 + (p0 & 63);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int px = q * 4 + (lane >> 4), ch = lane & 15;
+                const u32x4 v = *(const u32x4*)(stg + px * 256 + ((ch ^ px) << 4));
+                if (ty < H && tx + px < W)
+                    *(u32x4*)(outp + ((((long long)b * H + ty) * W + tx + px) * C) * 2 + ch * 16) = v;
             }
+            asm volatile("" ::: "memory");
+        }
+        if (ok) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
