@@ -177,6 +177,8 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
     const float* resb = a.res ? a.res + (long long)b * a.r_bs : nullptr;
     const f16_t* resh = a.res_f16 ? a.res_f16 + (long long)b * a.r_bs : nullptr;
     const bool wide16 = TC == 4 && (a.ldo % 8) == 0 && (a.o_bs % 8) == 0;
+    // whole cout tile real + only 16-bit outputs: they leave through the LDS transpose below (full 128-B lines per store)
+    const bool staged = wide16 && a.out_mode == 0 && (a.out_bf16 || a.out_f16) && c0 + BC <= a.Cout;
     unsigned valid = 0;
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
                 v += f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
             }
             if (a.out_f32) *(f32x4*)(a.out_f32 + ob + o) = v;
-            if (!(wide16 && cg0 + 16 <= a.Cout)) {
+            if (!staged && !(wide16 && cg0 + 16 <= a.Cout)) {
                 if (a.out_bf16) {
                     bf16x4 h;
                     h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
             acc[i][j] = v;
         }
         if constexpr (TC == 4) {
-            if (wide16 && cg0 + 16 <= a.Cout && a.out_mode == 0) {
+            if (!staged && wide16 && cg0 + 16 <= a.Cout && a.out_mode == 0) {
                 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
                 const long long o = ob + (long long)p * a.ldo + cg0;
 #pragma unroll
@@ -245,6 +247,56 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
                         for (int r = 0; r < 4; ++r) { h[r] = (f16_t)acc[i][j][r]; h[4 + r] = (f16_t)acc[i + 1][j][r]; }
                         *(f16x8*)(a.out_f16 + o + 4 * i) = h;
                     }
+                }
+            }
+        }
+    }
+    if constexpr (TC == 4) {
+        if (staged) {
+            // In the accumulator layout neighbouring lanes are neighbouring ROWS of the output (ldo elements apart): a direct
+            // store touches 64 lines with 16 B each.  Epilogue-heavy launches (Q.K^T: 128 KB of scores per 8-K-step tile)
+            // are bound by that, so 16-bit outputs are transposed through the (now idle) stage buffers: per wave
+            // [row][64 couts] rows of 128 B + 16 B pad, re-read as 8 lanes x 16 B per row -> 8 full lines per store.
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            constexpr int RS = 144, RP = TP * 16 > 64 ? 64 : TP * 16, JP = RP / 16;   // rows per pass (LDS budget), row tiles per pass
+            static_assert(8 * RP * RS <= 2 * (BP + BC) * ROWB && (TP % JP) == 0, "staging fits the stage buffers");
+            __syncthreads();                                 // every wave has consumed its last fragments
+            char* R = smem + wave * (RP * RS);
+            const int cl = lane & 7, pl = lane >> 3;
+            const long long cb = ob + c0 + wc * (BC / WC) + cl * 8;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                char* outp = pass == 0 ? (char*)a.out_f16 : (char*)a.out_bf16;
+                if (!outp) continue;
+#pragma unroll
+                for (int j0 = 0; j0 < TP; j0 += JP) {
+#pragma unroll
+                    for (int jj = 0; jj < JP; ++jj)
+#pragma unroll
+                        for (int i = 0; i < TC; i += 2) {
+                            char* d = R + (jj * 16 + frow) * RS + fq * 32 + i * 8;
+                            if (pass == 0) {
+                                f16x8 h;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { h[r] = (f16_t)acc[i][j0 + jj][r]; h[4 + r] = (f16_t)acc[i + 1][j0 + jj][r]; }
+                                *(f16x8*)d = h;
+                            } else {
+                                bf16x8 h;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { h[r] = (bf16_t)acc[i][j0 + jj][r]; h[4 + r] = (bf16_t)acc[i + 1][j0 + jj][r]; }
+                                *(bf16x8*)d = h;
+                            }
+                        }
+                    asm volatile("" ::: "memory");           // (LDS executes one wave's accesses in order)
+#pragma unroll
+                    for (int k = 0; k < RP / 8; ++k) {
+                        const int row = k * 8 + pl;
+                        const int p = p0 + wp * (BP / WP) + j0 * 16 + row;
+                        const u32x4 v = *(const u32x4*)(R + row * RS + cl * 16);
+                        if (p < HWo) *(u32x4*)(outp + (cb + (long long)p * a.ldo) * 2) = v;
+                    }
+                    asm volatile("" ::: "memory");
                 }
             }
         }
