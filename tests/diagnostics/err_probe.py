@@ -1,7 +1,7 @@
 """Latent error of the HIP encoder vs the fp32 oracle under the precision switches (flag 5: MFMA conv_in, flag 4: fp16 residual
-stream), next to the oracle's own bf16-operand emulation.  python tools/err_probe.py"""
+stream), next to the oracle's own bf16-operand emulation.  python tests/diagnostics/err_probe.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import encoder_ref
 from vae_tagger_amd import synth

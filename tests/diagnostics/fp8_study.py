@@ -1,8 +1,8 @@
 """Numerics study for BASELINE.json configs[4] (fp8 weights on the fp8 MFMA path): how far do the latents move when the
 MFMA operands are rounded to fp8 e4m3 instead of bf16?  CPU only, small image; uses the oracle's rounding hooks.
-   python tools/fp8_study.py            (prints max |d latent| vs the fp32 oracle for bf16, fp8 weights, fp8 weights+activations)"""
+   python tests/diagnostics/fp8_study.py            (prints max |d latent| vs the fp32 oracle for bf16, fp8 weights, fp8 weights+activations)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import encoder_ref
 from vae_tagger_amd import synth

@@ -1,7 +1,7 @@
 """Parity sweep over every reachable aspect-ratio bucket (reference AspectRatioBucketing(512, 1024, 64), modules.py:180-222):
-one image per bucket through the HIP encoder + decoder against the CPU oracle.  python tools/sweep_buckets.py [stride]"""
+one image per bucket through the HIP encoder + decoder against the CPU oracle.  python tests/diagnostics/sweep_buckets.py [stride]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import decoder_ref, encoder_ref
 from vae_tagger_amd import synth
