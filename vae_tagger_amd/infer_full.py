@@ -74,6 +74,15 @@ def load_models(args, device="cuda"):
     return vae_model, decoder, tags_df["name"].tolist()
 
 
+def _require_finite(a, what):
+    """The residual stream and the attention scores are stored as fp16 on the device: activations beyond +-65504 (not seen
+    with PyTorch-init weights) would surface here as inf/nan instead of as silently wrong tags."""
+    import numpy as np
+    if not np.isfinite(a).all():
+        raise FloatingPointError(f"non-finite {what}: activations left the fp16 range of the residual stream; "
+                                 "rerun with fp32 storage (vt_set_flag(ctx, 4, 0))")
+
+
 def summarize(conf_row, idx_row, tag_names, threshold):
     """One image's JSON entry from its sorted confidences / indices (infer_full.py:106-125)."""
     predicted = []
@@ -122,6 +131,7 @@ def infer_and_classify(args):
             x = torch.stack(batch).to(device)
             conf, idx = pipe.tag(x)
             conf, idx = conf.cpu().numpy(), idx.cpu().numpy()
+            _require_finite(conf, "confidences")
             for k, p in enumerate(names):
                 results[str(p)] = summarize(conf[k], idx[k], tag_names, args.confidence_threshold)
                 processed += 1

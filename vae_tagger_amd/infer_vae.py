@@ -57,6 +57,8 @@ def infer_and_save_latents(args):
         try:
             latent = vae_model.encode(torch.stack(batch).to(device))
             flat = latent.reshape(latent.size(0), -1).cpu().numpy()
+            from .infer_full import _require_finite
+            _require_finite(flat, "latents")
             for k, p in enumerate(names):
                 latent_data[str(p)] = flat[k].tolist()
                 processed += 1
