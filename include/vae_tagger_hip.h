@@ -105,7 +105,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         4-wave x 256-VGPR tile (16x16 px x 128 couts), 2 = only the 128-cout layers on it, 1 = the 128-cout layers on
  *         the 8-wave x 128-VGPR tile, 0 = one workgroup per CU (16x16 px x 256 couts / 32x16 px x 128 couts).
  * flag 4: 1 (default) = the residual stream between resnet blocks is STORED as fp16 (all arithmetic stays fp32;
- *         halves the HBM traffic of the conv2 epilogues and of norm1), 0 = stored as fp32.
+ *         halves the HBM traffic of the conv2 epilogues and of norm1) and each block's conv1 output as fp16 instead of
+ *         bf16 (read only by norm2), 0 = stored as fp32 / bf16.
  * flag 5: 1 (default) = conv_in (3 -> 128 channels) runs on the matrix cores from a bf16 im2col operand,
  *         0 = exact fp32 VALU conv.
  * flag 6: 1 (default) = 1x1 / GEMM launches with K <= 512 and no statistics epilogue (resnet shortcuts, attention

@@ -658,12 +658,17 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             if ((rr = run_conv(c, rw.sc, h16_for_shortcut, B, h, w, 1, 0, h, w, nullptr, f32[scb], nullptr, s, nullptr, 32, nullptr, nullptr, rdt))) return rr;
             res = f32[scb];
         }
-        if ((rr = run_norm_conv(c, rw.n1, rw.c1, f32[cur], rdt, B, h, w, e.groups, act, nullptr, nullptr, tmid, gn, true, s, rdt))) return rr;
+        // conv1's output is only ever read by norm2: with the fp16 storage mode it is kept as fp16 too (11 significand
+        // bits instead of bf16's 8 at the same 2 B: one of the three 8-bit roundings per resnet block disappears)
+        const bool c1h = rdt == 2;
+        const int c1dt = c1h ? 2 : 0;
+        if ((rr = run_norm_conv(c, rw.n1, rw.c1, f32[cur], rdt, B, h, w, e.groups, act, nullptr, c1h ? (void*)tmid : nullptr,
+                                c1h ? nullptr : tmid, gn, true, s, rdt))) return rr;
         if (want_bf16_out) {
             // the only consumer is the downsample conv (bf16 operand, no norm): skip the fp32 copy of h and the stats
-            return run_norm_conv(c, rw.n2, rw.c2, tmid, 0, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt);
+            return run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt);
         }
-        if ((rr = run_norm_conv(c, rw.n2, rw.c2, tmid, 0, B, h, w, e.groups, act, res, f32[nxt], nullptr, gn, true, s, rdt))) return rr;
+        if ((rr = run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, f32[nxt], nullptr, gn, true, s, rdt))) return rr;
         cur = nxt;
         return VT_OK;
     };
