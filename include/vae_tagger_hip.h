@@ -112,6 +112,10 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  * flag 6: 1 (default) = 1x1 / GEMM launches with K <= 512 and no statistics epilogue (resnet shortcuts, attention
  *         projections, Q.K^T) and the 128-cout stride-2 conv use a 192x128 tile at two workgroups per CU,
  *         0 = the 256x256 / 256x128 tiles (process-wide).
+ * flag 7: mid-block attention softmax. 0 (default) = no softmax pass: Q.K^T stores exp(s - c_i) (c_i from operand norms),
+ *         P.V divides by the row sums; a launch group whose norm bound is too loose is flagged on the device and takes c_i
+ *         = the exact row maximum from an extra, otherwise gated-off Q.K^T pass.  1 = always the exact row maximum.
+ *         2 = fp16 scores, a row-softmax pass, bf16 P.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

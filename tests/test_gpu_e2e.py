@@ -61,9 +61,10 @@ def test_encoder_matches_oracle_on_odd_shapes(vae, h, w):
 
 
 @pytest.mark.parametrize("flags", [(0, 0, 0, 1, 1, 1), (1, 0, 0, 1, 1, 0), (1, 1, 0, 1, 1, 1), (1, 1, 1, 1, 0, 1), (1, 1, 0, 0, 0, 0), (1, 1, 0, 1, 0, 1),
-                                   (1, 1, 0, 2, 1, 1), (1, 1, 0, 3, 1, 1), (1, 0, 0, 3, 0, 0)])
+                                   (1, 1, 0, 2, 1, 1), (1, 1, 0, 3, 1, 1), (1, 0, 0, 3, 0, 0), (1, 1, 0, 3, 1, 1, 0, 1), (1, 1, 0, 3, 1, 1, 1, 2)])
 def test_encoder_kernel_variants_agree(vae, flags):
-    """flags: (halo conv kernel, epilogue GroupNorm statistics, fused apply, 2-workgroup tile mode 0..3, fp16 residual storage, MFMA conv_in):
+    """flags: (halo conv kernel, epilogue GroupNorm statistics, fused apply, 2-workgroup tile mode 0..3, fp16 residual storage, MFMA conv_in
+    [, short-K GEMM tile, attention softmax mode 0..2]):
     every combination stays within the bf16 tolerance of the fp32 oracle."""
     sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
     x = synth.synth_images(2, 96, 160, seed=17)
@@ -74,7 +75,7 @@ def test_encoder_kernel_variants_agree(vae, flags):
             ctx.call("vt_set_flag", f, v)
         lat = vae.encode(x.cuda()).cpu()
     finally:
-        for f, v in enumerate((1, 1, 0, 3, 1, 1)):
+        for f, v in enumerate((1, 1, 0, 3, 1, 1, 1, 0)):
             ctx.call("vt_set_flag", f, v)
     assert (lat - ref).abs().max().item() <= TOL_LATENT_BF16
 
@@ -182,6 +183,50 @@ def test_device_preprocess_is_bit_exact_with_totensor_normalize(vae):
     ref = (u8.permute(0, 3, 1, 2).to(torch.float32).div(255.0) - 0.5) / 0.5       # ToTensor + Normalize(0.5, 0.5)
     got = pipe.normalize_u8(u8.cuda()).cpu()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("gain,S", [(1.0, 200), (6.0, 200), (1.0, 1024), (6.0, 333)])
+def test_mid_attention_without_softmax_pass(gain, S):
+    """vt_op_attention (E5): the default path has no softmax pass -- Q.K^T emits exp(s - c_i) with c_i from operand norms,
+    P.V divides by the row sums.  Every mode stays on the fp32 reference; with to_q / to_k scaled by 6 the norm bound is
+    too loose (u - l > 120), the launch group is flagged and c_i is the exact row maximum: bit-identical to mode 1."""
+    import ctypes
+    from vae_tagger_amd.diffusers_vae_loader import get_diffusers_vae_config, load_diffusers_vae_from_config
+    from _util import vp
+    sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    A = "encoder.mid_block.attentions.0."
+    for k in ("to_q", "to_k"):
+        sd[A + k + ".weight"] = sd[A + k + ".weight"] * gain
+        sd[A + k + ".bias"] = sd[A + k + ".bias"] * gain
+    m = load_diffusers_vae_from_config(get_diffusers_vae_config())
+    m.load_state_dict(sd, strict=False)
+    ctx = m.to("cuda").eval()._context()
+    B, C = 3, 512
+    g = torch.Generator().manual_seed(int(gain) * 1000 + S)
+    x = torch.randn(B, S, C, generator=g).bfloat16()
+    res = torch.randn(B, S, C, generator=g)
+    bf = lambda w: w.bfloat16().float()
+    q = bf(x.float() @ bf(sd[A + "to_q.weight"]).t() + sd[A + "to_q.bias"])
+    k = bf(x.float() @ bf(sd[A + "to_k.weight"]).t() + sd[A + "to_k.bias"])
+    v = bf(x.float() @ bf(sd[A + "to_v.weight"]).t() + sd[A + "to_v.bias"])
+    o = torch.softmax(q @ k.transpose(1, 2) / C ** 0.5, dim=-1) @ v
+    ref = o @ bf(sd[A + "to_out.0.weight"]).t() + sd[A + "to_out.0.bias"] + res
+    ws = torch.empty(ctx.lib.vt_op_attention_workspace_bytes(B, S, C), dtype=torch.uint8, device="cuda")
+    xd, rd = x.cuda(), res.cuda()
+    outs = []
+    try:
+        for mode in (0, 1, 2):
+            ctx.call("vt_set_flag", 7, mode)
+            out = torch.full((B, S, C), float("nan"), device="cuda")
+            ctx.call("vt_op_attention", vp(xd), vp(rd), vp(out), B, S, C, vp(ws), ctypes.c_void_p(0))
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        ctx.call("vt_set_flag", 7, 0)
+    for out in outs:
+        assert (out - ref).abs().max().item() <= 2e-2           # bf16 P and o: ~4e-3 relative on |o| <= max|v|
+    assert (outs[0] - outs[1]).abs().max().item() <= 1e-2
+    assert torch.equal(outs[0], outs[1]) == (gain > 1)          # flagged <=> the exact-maximum path ran
 
 
 def test_evaluation_caller_matches_oracle(vae, tmp_path):

@@ -81,6 +81,7 @@ struct vt_context {
     int fuse_gn_stats = 1;          // vt_set_flag(ctx, 1, v)
     int fuse_gn_apply = 0;          // vt_set_flag(ctx, 2, v): break-even on MI355X today, off by default
     int res_fp16 = 1;               // vt_set_flag(ctx, 4, v): residual stream stored as fp16 (math stays fp32)
+    int attn_mode = 0;              // vt_set_flag(ctx, 7, v): see run_attention
     // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
     int* rs_host = nullptr; size_t rs_host_ints = 0; hipEvent_t rs_event = nullptr;
     int conv_in_mfma = 1;           // vt_set_flag(ctx, 5, v): conv_in on the matrix cores (bf16 im2col), else exact fp32 VALU
@@ -189,7 +190,7 @@ int get_linear_bf16(vt_context* c, const std::string& name, int out, int in, std
 
 // ---- launch helpers -------------------------------------------------------------------------------
 hipError_t launch_gemm(vt_context* c, const ConvGemmArgs& a, hipStream_t s) {
-    if (!c->profiling) return vt_launch_conv_gemm(a, s);
+    if (!c->profiling || a.gate) return vt_launch_conv_gemm(a, s);       // gated launches may be no-ops: not counted
     vt_context::ProfRec r;
     r.e0 = c->next_event(); r.e1 = c->next_event();
     if (!r.e0 || !r.e1) return hipErrorOutOfMemory;
@@ -316,10 +317,14 @@ int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, 
                     groups, xdt == 1 ? (const float*)x : nullptr, gn.ss, rdt);
 }
 
-struct AttnScratch { bf16_t* qk; bf16_t* vt; f16_t* scores; bf16_t* probs; bf16_t* o; int group; };
+struct AttnScratch {
+    bf16_t* qk; bf16_t* vt; f16_t* scores; bf16_t* probs; bf16_t* o;
+    float* qn; float* kn; float* sd; float* shift; float* rinv; float* part; int* flags;
+    int group;
+};
 
-// Scores and probabilities are materialised for `group` images at a time (one batched launch each for Q.K^T,
-// softmax and P.V): as many images as fit an 8 GiB budget (1 GiB per image at S = 16384).
+// Probabilities (and, on the three-pass path, scores) are materialised for `group` images at a time (one batched launch
+// each for Q.K^T and P.V): as many images as fit an 8 GiB budget (1 GiB per image at S = 16384).
 int attn_group(int B, int S) {
     const size_t ld = (size_t)(S + 7) / 8 * 8;
     const size_t per_img = (size_t)S * ld * 4;                      // fp16 scores + bf16 probs
@@ -328,10 +333,13 @@ int attn_group(int B, int S) {
     if (g > (size_t)B) g = (size_t)B;
     return (int)g;
 }
+// (row, column slot) partials per row: every tile configuration gives a wave 64 columns (the 32-column one has one slot)
+size_t attn_slots_bound(int S) { return (size_t)(S + 7) / 8 * 8 / 64 + 4; }
 size_t attn_scratch_bytes(int B, int S, int C) {
     const size_t ld = (size_t)(S + 7) / 8 * 8, G = (size_t)attn_group(B, S);
     return align_up((size_t)B * S * 2 * C * 2) + align_up((size_t)B * C * ld * 2) + align_up(G * S * ld * 2) +
-           align_up(G * S * ld * 2) + align_up((size_t)B * S * C * 2);
+           align_up(G * S * ld * 2) + align_up((size_t)B * S * C * 2) + 5 * align_up((size_t)B * S * 4) +
+           align_up(G * attn_slots_bound(S) * S * 4) + align_up((size_t)B * 4);
 }
 AttnScratch carve_attn(char* p, int B, int S, int C) {
     const size_t ld = (size_t)(S + 7) / 8 * 8, G = (size_t)attn_group(B, S);
@@ -341,7 +349,14 @@ AttnScratch carve_attn(char* p, int B, int S, int C) {
     a.vt = (bf16_t*)p; p += align_up((size_t)B * C * ld * 2);
     a.scores = (f16_t*)p; p += align_up(G * S * ld * 2);
     a.probs = (bf16_t*)p; p += align_up(G * S * ld * 2);
-    a.o = (bf16_t*)p;
+    a.o = (bf16_t*)p; p += align_up((size_t)B * S * C * 2);
+    a.qn = (float*)p; p += align_up((size_t)B * S * 4);
+    a.kn = (float*)p; p += align_up((size_t)B * S * 4);
+    a.sd = (float*)p; p += align_up((size_t)B * S * 4);
+    a.shift = (float*)p; p += align_up((size_t)B * S * 4);
+    a.rinv = (float*)p; p += align_up((size_t)B * S * 4);
+    a.part = (float*)p; p += align_up(G * attn_slots_bound(S) * S * 4);
+    a.flags = (int*)p;
     return a;
 }
 
@@ -363,21 +378,51 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
     a.Win = a.Wout = C; a.Cin = C; a.Cout = ld; a.Wrows = S; a.ldx = C; a.ldw = C; a.ldo = ld;
     a.x_bs = 0; a.w_bs = (long long)S * C; a.o_bs = (long long)C * ld; a.batch = B;
     HIPCK(c, launch_gemm(c, a, s), "attn v proj");
+    const float scale = 1.0f / sqrtf((float)C);
+    const int mode = c->attn_mode;                  // 0: exponent shift from operand norms, exact row maximum if flagged;
+                                                    // 1: always the exact row maximum; 2: scores -> softmax pass -> P
+    if (mode == 0) {
+        HIPCK(c, hipMemsetAsync(sc.flags, 0, (size_t)((B + sc.group - 1) / sc.group) * 4, s), "attn flags");
+        HIPCK(c, vt_launch_attn_row_norms(sc.qk, (long long)B * S, C, sc.qn, sc.kn, sc.sd, s), "attn row norms");
+        HIPCK(c, vt_launch_attn_shift(sc.qn, sc.kn, sc.sd, B, S, scale, 120.f, sc.shift, sc.flags, sc.group, s), "attn shift");
+    }
     for (int b0 = 0; b0 < B; b0 += sc.group) {
         const int nb = (B - b0 < sc.group) ? B - b0 : sc.group;
         const bf16_t* q = sc.qk + (long long)b0 * S * 2 * C;
-        // scores = q k^T / sqrt(C) -> fp16 [nb][S][ld]   (|s| is O(1): fp16's 2^-11 is far below the bf16 rounding of P)
-        a.X = q; a.W = q + C; a.bias = nullptr; a.bias_mode = 0; a.out_bf16 = nullptr; a.out_f32 = nullptr; a.out_f16 = sc.scores;
+        // s = q k^T / sqrt(C), [nb][S][ld]
+        a.X = q; a.W = q + C; a.bias = nullptr; a.bias_mode = 0; a.out_bf16 = nullptr; a.out_f32 = nullptr; a.out_f16 = nullptr;
         a.Win = a.Wout = S; a.Cin = C; a.Cout = ld; a.Wrows = S; a.ldx = 2 * C; a.ldw = 2 * C; a.ldo = ld;
-        a.x_bs = a.w_bs = (long long)S * 2 * C; a.o_bs = (long long)S * ld; a.batch = nb; a.alpha = 1.0f / sqrtf((float)C);
-        HIPCK(c, launch_gemm(c, a, s), "attn scores");
-        HIPCK(c, vt_launch_softmax_rows(sc.scores, 1, sc.probs, (long long)nb * S, S, ld, ld, s), "attn softmax");
-        // o = P v -> bf16 [nb][S][C]
+        a.x_bs = a.w_bs = (long long)S * 2 * C; a.o_bs = (long long)S * ld; a.batch = nb; a.alpha = scale;
+        a.row_mode = 0; a.row_in = nullptr; a.row_part = nullptr; a.row_bs = S; a.gate = nullptr; a.gate_expect = 0;
+        float* shift = sc.shift + (long long)b0 * S;
+        float* rinv = sc.rinv + (long long)b0 * S;
+        if (mode == 2) {
+            // fp16 scores (|s| is O(1): fp16's 2^-11 is far below the bf16 rounding of P), one softmax pass over them
+            a.out_f16 = sc.scores;
+            HIPCK(c, launch_gemm(c, a, s), "attn scores");
+            HIPCK(c, vt_launch_softmax_rows(sc.scores, 1, sc.probs, (long long)nb * S, S, ld, ld, s), "attn softmax");
+        } else {
+            const int slots = vt_conv_gemm_col_slots(a);
+            if ((size_t)slots > attn_slots_bound(S)) return c->fail(VT_ERR_WORKSPACE, "attention: %d column slots exceed the scratch", slots);
+            const int* gate = mode == 0 ? sc.flags + b0 / sc.group : nullptr;
+            // exact row maxima (always in mode 1; in mode 0 only when the operand-norm bound was too loose for this group)
+            a.row_mode = 1; a.row_part = sc.part; a.gate = gate; a.gate_expect = 1;
+            HIPCK(c, launch_gemm(c, a, s), "attn row max");
+            HIPCK(c, vt_launch_attn_row_reduce(sc.part, slots, S, S, nb, 0, shift, gate, 1, s), "attn row max reduce");
+            // P~ = exp(s - shift) as bf16 + the row sums of what was stored
+            a.row_mode = 2; a.row_in = shift; a.out_bf16 = sc.probs; a.gate = nullptr;
+            HIPCK(c, launch_gemm(c, a, s), "attn exp scores");
+            HIPCK(c, vt_launch_attn_row_reduce(sc.part, slots, S, S, nb, 1, rinv, nullptr, 0, s), "attn row sums");
+        }
+        // o = P v -> bf16 [nb][S][C]   (rows of P~ scaled by 1 / row sum in the epilogue)
         a.X = sc.probs; a.W = sc.vt + (long long)b0 * C * ld; a.out_f16 = nullptr; a.out_bf16 = sc.o + (long long)b0 * S * C;
         a.Cin = ld; a.Cout = C; a.Wrows = C; a.ldx = ld; a.ldw = ld; a.ldo = C; a.alpha = 1.f;
         a.x_bs = (long long)S * ld; a.w_bs = (long long)C * ld; a.o_bs = (long long)S * C;
+        a.row_part = nullptr; a.gate = nullptr;
+        if (mode == 2) { a.row_mode = 0; a.row_in = nullptr; } else { a.row_mode = 3; a.row_in = rinv; }
         HIPCK(c, launch_gemm(c, a, s), "attn pv");
     }
+    a.row_mode = 0; a.row_in = nullptr;
     // out = o Wo^T + bo + residual -> fp32 [B][S][C]
     a.X = sc.o; a.W = w.wo; a.bias = w.bo; a.bias_mode = 1; a.out_bf16 = nullptr;
     if (rdt == 1) { a.res = (const float*)res; a.out_f32 = (float*)out; } else { a.res_f16 = (const f16_t*)res; a.out_f16 = (f16_t*)out; }
@@ -877,6 +922,11 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 4) { c->res_fp16 = value != 0; return VT_OK; }
     if (flag == 5) { c->conv_in_mfma = value != 0; return VT_OK; }
     if (flag == 6) { vt_conv_gemm_set_short(value); return VT_OK; }         // process-wide: GEMM tile choice
+    if (flag == 7) {
+        if (value < 0 || value > 2) return c->fail(VT_ERR_INVALID, "vt_set_flag(7): value %d not in 0..2", value);
+        c->attn_mode = value;
+        return VT_OK;
+    }
     return c->fail(VT_ERR_INVALID, "vt_set_flag: unknown flag %d", flag);
 }
 

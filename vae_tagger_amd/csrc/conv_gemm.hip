@@ -30,8 +30,9 @@ constexpr int ROWB = BK * 2;      // bytes per LDS row
 
 // OCC2: compiled for two workgroups per CU (<= 128 VGPRs; the launcher checks the LDS fits twice): the latency-bound
 // short-K launches (1x1 shortcuts, attention projections, Q.K^T) overlap one workgroup's prologue / epilogue with the other's MFMAs.
-template <int BP, int BC, int WP, int WC, bool OCC2 = false>
-__global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+// one output tile; `logical` = tile index in [0, ptiles * ctiles * batch)
+template <int BP, int BC, int WP, int WC>
+__device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem, int logical) {
     static_assert(WP * WC == 8, "8 waves per workgroup");
     constexpr int TP = BP / WP / 16;          // 16-pixel MFMA tiles per wave
     constexpr int TC = BC / WC / 16;          // 16-cout MFMA tiles per wave
@@ -40,8 +41,6 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
     constexpr int NXJ = (XI + 7) / 8;         // per wave
     constexpr int NWJ = (WI + 7) / 8;
     constexpr int STAGE_BYTES = (BP + BC) * ROWB;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -52,7 +51,6 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
     const int ptiles = (HWo + BP - 1) / BP;
     const int ctiles = (a.Cout + BC - 1) / BC;
     const int per_img = ptiles * ctiles;
-    int logical = vt_xcd_remap(blockIdx.x, gridDim.x);
     const int b = logical / per_img;
     logical -= b * per_img;
     const int p0 = (logical / ctiles) * BP;
@@ -186,11 +184,30 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
         if (p >= HWo) continue;
         valid |= 1u << j;
         const int cg0 = c0 + wc * (BC / WC) + (TC == 4 ? fq * 16 : fq * 4);
+        const float rin = a.row_in ? a.row_in[(long long)b * a.row_bs + p] : 0.f;
+        float racc = a.row_mode == 1 ? -__builtin_inff() : 0.f;
+        const float alpha2 = a.alpha * 1.44269504f, rin2 = rin * 1.44269504f;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int cg = cg0 + (TC == 4 ? i * 4 : i * 16);
             if (cg >= a.Cout) continue;
             f32x4 v = acc[i][j] * a.alpha;
+            if (a.row_mode) {
+                if (a.row_mode == 3) {
+                    v *= rin;
+                } else if (a.row_mode == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {      // exp(alpha*acc - rin) as one fma + v_exp_f32
+                        v[r] = cg + r < a.Wrows ? (float)(bf16_t)__builtin_amdgcn_exp2f(fmaf(acc[i][j][r], alpha2, -rin2)) : 0.f;
+                        racc += v[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (cg + r < a.Wrows) racc = fmaxf(racc, v[r]);
+                    continue;
+                }
+            }
             if (a.bias_mode == 1) {
                 const f32x4 bv = *(const f32x4*)(a.bias + cg);
                 v += bv;
@@ -228,6 +245,15 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
                 }
             }
             acc[i][j] = v;
+        }
+        if (a.row_part) {
+            // the four fq lanes of a row hold this wave's other columns of it
+            const float o1 = __shfl_xor(racc, 16);
+            racc = a.row_mode == 1 ? fmaxf(racc, o1) : racc + o1;
+            const float o2 = __shfl_xor(racc, 32);
+            racc = a.row_mode == 1 ? fmaxf(racc, o2) : racc + o2;
+            const int slots = ctiles * WC;
+            if (fq == 0) a.row_part[((long long)b * slots + (c0 / BC) * WC + wc) * a.row_bs + p] = racc;
         }
         if constexpr (TC == 4) {
             if (!staged && wide16 && cg0 + 16 <= a.Cout && a.out_mode == 0) {
@@ -312,13 +338,33 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const Conv
 }
 
 template <int BP, int BC, int WP, int WC, bool OCC2 = false>
+__global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_gemm_tile<BP, BC, WP, WC>(a, smem, vt_xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Gated launches (a.gate: usually a no-op decided on the device) run as a small resident grid that walks the tiles, so a
+// launch that turns out to be a no-op costs 512 workgroup dispatches instead of one per tile (0.6 ms for Q.K^T at 16 x 1024^2).
+template <int BP, int BC, int WP, int WC, bool OCC2 = false>
+__global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_gated_kernel(const ConvGemmArgs a, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (*a.gate != a.gate_expect) return;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        conv_gemm_tile<BP, BC, WP, WC>(a, smem, t);
+        __syncthreads();                                   // the epilogue may still be reading the stage buffers
+    }
+}
+
+template <int BP, int BC, int WP, int WC, bool OCC2 = false>
 hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BP + BC) * ROWB;
     static_assert(!OCC2 || smem <= 80 * 1024, "two workgroups per CU");
     static bool attr_set = false;
     auto kern = conv_gemm_kernel<BP, BC, WP, WC, OCC2>;
+    auto gated = conv_gemm_gated_kernel<BP, BC, WP, WC, OCC2>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gated, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -326,7 +372,8 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     const int ptiles = (HWo + BP - 1) / BP, ctiles = (a.Cout + BC - 1) / BC;
     const long long nblk = (long long)ptiles * ctiles * a.batch;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), smem, s, a);
+    if (a.gate) hipLaunchKernelGGL(gated, dim3((unsigned)(nblk < 512 ? nblk : 512)), dim3(512), smem, s, a, (int)nblk);
+    else hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), smem, s, a);
     return hipGetLastError();
 }
 
@@ -347,6 +394,11 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
         const int bc = a.Cout <= 32 ? 32 : (a.Cout <= 128 ? 128 : 256);
         if (a.out_mode != 0 || (a.Cout % bc) || a.Cout <= 32) return hipErrorInvalidValue;
     }
+    if (a.row_mode < 0 || a.row_mode > 3 || (a.row_mode != 0 && (a.out_mode != 0 || a.gn_partial || a.row_bs < (long long)a.Hout * a.Wout)))
+        return hipErrorInvalidValue;
+    if ((a.row_mode == 2 || a.row_mode == 3) != (a.row_in != nullptr)) return hipErrorInvalidValue;
+    if ((a.row_mode == 1 || a.row_mode == 2) != (a.row_part != nullptr)) return hipErrorInvalidValue;
+    if (a.row_mode == 1 && (a.out_f32 || a.out_bf16 || a.out_f16)) return hipErrorInvalidValue;
     // per-image offsets are 32-bit
     if ((long long)a.Hin * a.Win * a.ldx >= (1LL << 31)) return hipErrorInvalidValue;
     if ((long long)a.Wrows * a.ldw >= (1LL << 31)) return hipErrorInvalidValue;
@@ -368,6 +420,13 @@ int vt_conv_gemm_ptiles_of(const ConvGemmArgs& a) {
     const int cfg = vt_conv_gemm_config(a);
     const int bp = cfg == 0 ? 128 : (cfg == 9 ? 192 : 256);
     return (a.Hout * a.Wout + bp - 1) / bp;
+}
+
+// (row, column slot) partials per row a row_mode 1 / 2 launch writes
+int vt_conv_gemm_col_slots(const ConvGemmArgs& a) {
+    const int cfg = vt_conv_gemm_config(a);
+    const int bc = cfg == 0 ? 32 : (cfg == 2 ? 256 : 128), wc = cfg == 0 ? 1 : (cfg == 2 ? 4 : 2);
+    return (a.Cout + bc - 1) / bc * wc;
 }
 
 int g_gemm_short = 1;      // short-K launches without a statistics epilogue use the two-workgroups-per-CU tile (vt_set_flag 6)

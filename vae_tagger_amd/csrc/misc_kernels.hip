@@ -580,3 +580,104 @@ hipError_t vt_launch_softmax_rows(const void* scores, int scores_f16, bf16_t* pr
     return scores_f16 ? softmax_dispatch((const f16_t*)scores, probs, rows, n, lds, ldp, s)
                       : softmax_dispatch((const float*)scores, probs, rows, n, lds, ldp, s);
 }
+
+// ---- attention without a softmax pass (capi.hip run_attention) -------------------------------------------------------------
+// softmax(s)_ij = exp(s_ij - c_i) / sum_j exp(s_ij - c_i) for ANY per-row c_i, so the Q.K^T epilogue can emit the
+// numerators directly once a c_i is known that keeps them inside the float range.  From the operands alone:
+// s_ij <= |q_i| max_j|k_j| alpha =: u_i (Cauchy-Schwarz) and max_j s_ij >= s_ii =: l_i (self-attention: the diagonal exists).
+// With c_i = (u_i + l_i) / 2 every numerator is <= exp((u_i - l_i) / 2) and the diagonal one is >= exp(-(u_i - l_i) / 2):
+// while u_i - l_i <= 120 nothing overflows (16384 * e^60 * |v| << 3e38) and no row sum underflows.  Beyond that
+// the launch group is flagged and c_i becomes the exact row maximum from an extra Q.K^T pass.
+namespace {
+
+// one wave per token: |q|^2, |k|^2, q.k of row i of the [rows][2C] q|k buffer
+__global__ __launch_bounds__(256) void attn_row_norms_kernel(const bf16_t* __restrict__ qk, long long rows, int C,
+                                                             float* __restrict__ qn, float* __restrict__ kn, float* __restrict__ sd) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const bf16_t* q = qk + row * 2 * C;
+    float a = 0.f, b = 0.f, d = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        const bf16x8 qv = *(const bf16x8*)(q + c), kv = *(const bf16x8*)(q + C + c);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float x = (float)qv[r], y = (float)kv[r];
+            a += x * x; b += y * y; d += x * y;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); d += __shfl_xor(d, o); }
+    if (lane == 0) { qn[row] = a; kn[row] = b; sd[row] = d; }
+}
+
+// one block per image: c_i and the "bound too loose" flag of the group the image belongs to
+__global__ __launch_bounds__(1024) void attn_shift_kernel(const float* __restrict__ qn, const float* __restrict__ kn,
+                                                          const float* __restrict__ sd, int S, float alpha, float max_gap,
+                                                          float* __restrict__ shift, int* __restrict__ flags, int group) {
+    __shared__ float red[16];
+    const long long base = (long long)blockIdx.x * S;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < S; i += 1024) m = fmaxf(m, kn[base + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    // a hair above the exact norms: the MFMA's fp32 accumulation order is not this kernel's
+    const float kmax = sqrtf(m) * alpha * 1.0001f;
+    bool loose = false;
+    for (int i = threadIdx.x; i < S; i += 1024) {
+        const float u = sqrtf(qn[base + i]) * kmax, l = sd[base + i] * alpha;
+        shift[base + i] = 0.5f * (u + l);
+        loose |= !(u - l <= max_gap);              // NaN-safe: anything odd takes the exact path
+    }
+    if (__syncthreads_or(loose) && threadIdx.x == 0) atomicOr(flags + blockIdx.x / group, 1);
+}
+
+// row_part [batch][slots][row_bs] -> out [batch][row_bs]: the maximum (op 0) or 1 / sum (op 1) over the slots.
+// 64 rows per block, the slots dealt to 4 waves and combined in a fixed order (deterministic sums).
+__global__ __launch_bounds__(256) void attn_row_reduce_kernel(const float* __restrict__ part, int slots, long long row_bs, int S,
+                                                              int op, float* __restrict__ out, const int* gate, int gate_expect) {
+    if (gate && *gate != gate_expect) return;
+    __shared__ float red[4][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float r = op == 0 ? -__builtin_inff() : 0.f;
+    if (i < S) {
+        const float* p = part + (long long)blockIdx.y * slots * row_bs + i;
+        for (int s = g; s < slots; s += 4) {
+            const float v = p[(long long)s * row_bs];
+            r = op == 0 ? fmaxf(r, v) : r + v;
+        }
+    }
+    red[g][threadIdx.x & 63] = r;
+    __syncthreads();
+    if (g == 0 && i < S) {
+        const int l = threadIdx.x;
+        r = op == 0 ? fmaxf(fmaxf(red[0][l], red[1][l]), fmaxf(red[2][l], red[3][l])) : (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        out[(long long)blockIdx.y * row_bs + i] = op == 0 ? r : 1.f / r;
+    }
+}
+
+}  // namespace
+
+hipError_t vt_launch_attn_row_norms(const bf16_t* qk, long long rows, int C, float* qn, float* kn, float* sd, hipStream_t s) {
+    if (!qk || !qn || !kn || !sd || rows <= 0 || rows > 0x7fffffffLL || C <= 0 || (C % 8)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_row_norms_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, qk, rows, C, qn, kn, sd);
+    return hipGetLastError();
+}
+hipError_t vt_launch_attn_shift(const float* qn, const float* kn, const float* sd, int images, int S, float alpha, float max_gap,
+                                float* shift, int* flags, int group, hipStream_t s) {
+    if (!qn || !kn || !sd || !shift || !flags || images <= 0 || S <= 0 || group <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_shift_kernel, dim3(images), dim3(1024), 0, s, qn, kn, sd, S, alpha, max_gap, shift, flags, group);
+    return hipGetLastError();
+}
+hipError_t vt_launch_attn_row_reduce(const float* part, int slots, long long row_bs, int S, int batch, int op, float* out,
+                                     const int* gate, int gate_expect, hipStream_t s) {
+    if (!part || !out || slots <= 0 || S <= 0 || batch <= 0 || row_bs < S) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_row_reduce_kernel, dim3((S + 63) / 64, batch), dim3(256), 0, s, part, slots, row_bs, S, op, out, gate,
+                       gate_expect);
+    return hipGetLastError();
+}

@@ -27,7 +27,18 @@ struct ConvGemmArgs {
     int cout_keep;
     float post_scale, post_shift;
     int gn_cpg;             // channels per group for gn_partial (0 = off)
+    // row softmax pieces of the attention (capi.hip run_attention).  A (row, column slot) is one wave's 16*TC columns of a row:
+    // slot = column tile * WC + wave column, vt_conv_gemm_col_slots(a) of them.
+    int row_mode;           // 0 off; 1 = no output, row_part = max over the slot of alpha*acc (columns >= Wrows excluded);
+                            // 2 = the output is exp(alpha*acc - row_in[p]) (columns >= Wrows: 0), row_part = the slot's sum
+                            //     of the ROUNDED bf16 outputs; 3 = output rows are multiplied by row_in[p]
+    const float* row_in;    // [batch][row_bs]
+    float* row_part;        // [batch][slots][row_bs]
+    long long row_bs;
+    const int* gate;        // optional: the whole launch is a no-op unless *gate == gate_expect
+    int gate_expect;
 };
+int vt_conv_gemm_col_slots(const ConvGemmArgs& a);
 
 hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s);
 // which tile configuration the dispatcher picks for these args: 0 = 128x32, 1 = 256x128, 2 = 256x256
@@ -96,6 +107,13 @@ hipError_t vt_launch_resize_u8(const unsigned char* src, int src_h, int src_w, i
                                unsigned char* dst, int dst_h, int dst_w, const int* tab_h, int ksize_h, const int* tab_v,
                                int ksize_v, unsigned char* tmp, hipStream_t s);
 
+// attention without a softmax pass (misc_kernels.hip): row norms of q|k, the per-row exponent shift + "bound too loose" flag
+// per launch group, and the reduction of the Q.K^T epilogue's (row, column slot) partials (op 0 max, op 1 reciprocal of the sum)
+hipError_t vt_launch_attn_row_norms(const bf16_t* qk, long long rows, int C, float* qn, float* kn, float* sd, hipStream_t s);
+hipError_t vt_launch_attn_shift(const float* qn, const float* kn, const float* sd, int images, int S, float alpha, float max_gap,
+                                float* shift, int* flags, int group, hipStream_t s);
+hipError_t vt_launch_attn_row_reduce(const float* part, int slots, long long row_bs, int S, int batch, int op, float* out,
+                                     const int* gate, int gate_expect, hipStream_t s);
 // row softmax: scores fp32 or fp16 [rows][lds] -> probs bf16 [rows][ldp]; columns [n, ldp) are written as zero.
 hipError_t vt_launch_softmax_rows(const void* scores, int scores_f16, bf16_t* probs, long long rows, int n, int lds,
                                   int ldp, hipStream_t s);
