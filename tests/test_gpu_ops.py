@@ -173,9 +173,15 @@ def test_conv_in_matches_torch(ops, H, W):
     w = _rand((128, 3, 3, 3), 14, 27 ** -0.5)
     b = _rand((128,), 15, 0.1)
     ref = F.conv2d(x, w, b, padding=1)
-    got32, got16 = ops.conv_in(x, w, b)
-    assert torch.allclose(got32, ref, rtol=1e-5, atol=1e-5), (got32 - ref).abs().max()
-    assert torch.allclose(got16, bf16_round(ref), rtol=1e-2, atol=1e-2)
+    try:
+        for mfma in (0, 1):
+            # 0: exact fp32 VALU conv; 1: matrix cores with split (hi + lo) bf16 operands, ~2^-16 relative
+            ops.ctx.call("vt_set_flag", 5, mfma)
+            got32, got16 = ops.conv_in(x, w, b)
+            assert torch.allclose(got32, ref, rtol=1e-5, atol=1e-5 if mfma == 0 else 5e-5), (mfma, (got32 - ref).abs().max())
+            assert torch.allclose(got16, bf16_round(ref), rtol=1e-2, atol=1e-2)
+    finally:
+        ops.ctx.call("vt_set_flag", 5, 1)
 
 
 @pytest.mark.parametrize("rows,n", [(5, 64), (3, 108), (4, 101), (2, 4096), (2, 5000), (1, 16384), (1, 20000)])

@@ -188,6 +188,28 @@ int get_linear_bf16(vt_context* c, const std::string& name, int out, int in, std
     return VT_OK;
 }
 
+// conv_in_mfma_kernel's weights: [2 (hi, lo)][128 rows][32 k] bf16, rows in the interleaved cout order; w = hi + lo to ~2^-17;
+// the bias rides in k = 27..29 of the hi rows as three bf16 pieces (the kernel's operand is 1.0 there).
+std::vector<uint16_t> pack_conv_in_mfma(const float* w_o27, const float* bias) {
+    std::vector<uint16_t> pk((size_t)2 * 128 * 32, 0);
+    for (int o = 0; o < 128; ++o) {
+        const int row = (o & ~63) + vt_halo_row_of_cout(o & 63);
+        for (int k = 0; k < 27; ++k) {
+            const float f = w_o27[(size_t)o * 27 + k];
+            const uint16_t hi = f2bf(f);
+            pk[(size_t)row * 32 + k] = hi;
+            pk[(size_t)(128 + row) * 32 + k] = f2bf(f - bf2f(hi));
+        }
+        float rest = bias[o];
+        for (int k = 27; k < 30; ++k) {
+            const uint16_t piece = f2bf(rest);
+            pk[(size_t)row * 32 + k] = piece;
+            rest -= bf2f(piece);
+        }
+    }
+    return pk;
+}
+
 // ---- launch helpers -------------------------------------------------------------------------------
 hipError_t launch_gemm(vt_context* c, const ConvGemmArgs& a, hipStream_t s) {
     if (!c->profiling || a.gate) return vt_launch_conv_gemm(a, s);       // gated launches may be no-ops: not counted
@@ -566,11 +588,7 @@ int vt_encoder_finalize(vt_context* c) {
         e.conv_in_b = (const float*)c->upload(b->v.data(), b->v.size() * 4);
         if (!e.conv_in_w || !e.conv_in_b) return c->fail(VT_ERR_HIP, "upload failed for conv_in");
         if (c0 == 128 && e.groups == 32) {
-            std::vector<uint16_t> pk((size_t)128 * 32, 0);
-            for (int o = 0; o < 128; ++o) {
-                const int row = (o & ~63) + vt_halo_row_of_cout(o & 63);
-                for (int k = 0; k < 27; ++k) pk[(size_t)row * 32 + k] = f2bf(w->v[(size_t)o * 27 + k]);
-            }
+            const std::vector<uint16_t> pk = pack_conv_in_mfma(w->v.data(), b->v.data());
             e.conv_in_wpk = (const bf16_t*)c->upload(pk.data(), pk.size() * 2);
             if (!e.conv_in_wpk) return c->fail(VT_ERR_HIP, "upload failed for conv_in");
         }
@@ -1188,6 +1206,14 @@ int vt_op_conv_in(vt_context* c, const float* x, const float* w_oihw, const floa
     // are copied to the host, packed [27][Cout] and written into `ws` (>= 27*Cout*4 bytes).  Synchronises.
     std::vector<float> hw((size_t)Cout * 27), pk((size_t)Cout * 27);
     HIPCK(c, hipMemcpy(hw.data(), w_oihw, hw.size() * 4, hipMemcpyDeviceToHost), "vt_op_conv_in copy");
+    if (Cout == 128 && c->conv_in_mfma) {            // the matrix-core variant the encoder uses (vt_set_flag 5); ws >= 16 KB
+        std::vector<float> hb(128);
+        HIPCK(c, hipMemcpy(hb.data(), bias, 128 * 4, hipMemcpyDeviceToHost), "vt_op_conv_in copy");
+        const std::vector<uint16_t> pm = pack_conv_in_mfma(hw.data(), hb.data());
+        HIPCK(c, hipMemcpy(ws, pm.data(), pm.size() * 2, hipMemcpyHostToDevice), "vt_op_conv_in copy");
+        HIPCK(c, vt_launch_conv_in_mfma(x, (const bf16_t*)ws, bias, o32, (bf16_t*)o16, nullptr, nullptr, nullptr, B, H, W, (hipStream_t)stream), "vt_op_conv_in");
+        return VT_OK;
+    }
     for (int o = 0; o < Cout; ++o) for (int k = 0; k < 27; ++k) pk[(size_t)k * Cout + o] = hw[(size_t)o * 27 + k];
     HIPCK(c, hipMemcpy(ws, pk.data(), pk.size() * 4, hipMemcpyHostToDevice), "vt_op_conv_in copy");
     HIPCK(c, vt_launch_conv_in(x, (const float*)ws, bias, o32, (bf16_t*)o16, nullptr, nullptr, 0, nullptr, B, H, W, Cout, (hipStream_t)stream), "vt_op_conv_in");

@@ -128,22 +128,26 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// conv_in on the matrix cores (Cout == 128): the 27 taps x channels of each pixel become one K = 32 operand row
-// (im2col built in LDS from the fp32 halo, rounded to bf16), so the whole conv is ONE v_mfma_f32_16x16x32_bf16
-// K-step per 16x16 output tile; the kernel is then bound by its output write.  Workgroup = 4 waves, 8 rows x 64
-// pixels x 128 couts; LDS: fp32 halo 3 x 10 x 66 (reused for the statistics), X rows 512 x 64 B (64-B-row swizzle as in
-// conv3x3_halo) = 40 KB, four workgroups per CU; the 8 KB of weights go straight from L2 to registers.  Weight rows use the interleaved cout map: lane (fq, fr) holds couts 64*h + 16*fq + 4*i + r
-// of pixel fr (tile i of half h), i.e. 16 consecutive couts per half -> 32-B fp16 / 64-B fp32 stores.
-// wpk: [128 rows][32 k] bf16 in that row order, k = ci*9 + ky*3 + kx, k >= 27 zero.
+// conv_in on the matrix cores (Cout == 128): the 27 taps x channels of a pixel are one K = 32 operand row, so the conv
+// is one v_mfma_f32_16x16x32_bf16 K-step per 16x16 output tile -- three of them, because both operands are split into
+// bf16 hi + lo parts (x.w ~ xh.wh + xl.wh + xh.wl, relative error ~2^-16 instead of the 2^-9 of single bf16 operands:
+// the first layer's rounding was 5 % of the whole encoder's latent error).  K slots 27..29 carry the bias the same way
+// (operand 1.0 x three bf16 pieces of the bias), so accumulators start at zero.  The kernel is bound by its output write.
+// Workgroup = 4 waves, 8 rows x 64 pixels x 128 couts; LDS: fp32 halo 3 x 10 x 66 (reused for the statistics) + 4 KB of
+// store staging per wave = 24 KB.  A lane builds its operand fragment (8 k-values of one pixel) straight from the halo:
+// 8 ds_read_b32 at per-lane tap offsets.  The 16 KB of weights go from L2 to registers.  Weight rows use the interleaved
+// cout map: lane (fq, fr) holds couts 64*h + 16*fq + 4*i + r of pixel fr (tile i of half h), i.e. 16 consecutive couts
+// per half -> 32-B fp16 / 64-B fp32 pieces.
+// wpk: [2 (hi, lo)][128 rows][32 k] bf16 in that row order, k = ci*9 + ky*3 + kx; hi rows carry the bias in k = 27..29.
 constexpr int CM_ROWS = 8, CM_PIX = 64;
 __global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ o32,
                                                            bf16_t* __restrict__ o16, f16_t* __restrict__ oh,
                                                            float* __restrict__ gn_partial, int H, int W) {
-    constexpr int RW = CM_PIX + 2, RH = CM_ROWS + 2, NPX = CM_ROWS * CM_PIX, C = 128;
+    constexpr int RW = CM_PIX + 2, RH = CM_ROWS + 2, C = 128;
     __shared__ __attribute__((aligned(16))) float sin[3 * RH * RW];
-    __shared__ __attribute__((aligned(16))) char xs[NPX * 64];
-    float (*red)[32][3] = (float (*)[32][3])sin;       // statistics scratch: reuses the halo once the im2col is built
+    __shared__ __attribute__((aligned(16))) char stgbuf[4 * 4096];
+    float (*red)[32][3] = (float (*)[32][3])sin;       // statistics scratch: reuses the halo once every wave is done with it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, y0 = blockIdx.y * CM_ROWS, x0 = blockIdx.x * CM_PIX;
     for (int i = tid; i < 3 * RH * RW; i += 256) {
@@ -153,69 +157,61 @@ __global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __res
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long long)b * 3 + c) * H + iy) * W + ix];
         sin[i] = v;
     }
-    __syncthreads();
-    // im2col: pixel p = row*64 + col -> 32 bf16 (27 real), four 16-B chunks
-    for (int p = tid; p < NPX; p += 256) {
-        const int py = p >> 6, px = p & 63;
-        bf16_t v[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            if (k < 27) {
-                const int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
-                v[k] = (bf16_t)sin[(ci * RH + py + ky) * RW + px + kx];
-            } else v[k] = (bf16_t)0.f;
-        }
-        const int sw = ((p >> 2) & 1) << 1;
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            bf16x8 h;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) h[r] = v[ch * 8 + r];
-            *(bf16x8*)(xs + p * 64 + ((ch ^ sw) << 4)) = h;
-        }
-    }
-    __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
-    bf16x8 wf[8];
+    // byte offsets of this lane's 8 k-values (k = 8*fq + r) relative to the pixel's window origin; k >= 27 reads tap 0
+    int offb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = fq * 8 + r, kk = k < 27 ? k : 0;
+        const int ci = kk / 9, ky = (kk - ci * 9) / 3, kx = kk - ci * 9 - ky * 3;
+        offb[r] = ((ci * RH + ky) * RW + kx) * 4;
+    }
+    bf16x8 wh[8], wl[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        wf[i] = *(const bf16x8*)(wpk + (i * 16 + fr) * 32 + fq * 8);   // 8 KB of weights, L2-resident: straight to registers
+        wh[i] = *(const bf16x8*)(wpk + (i * 16 + fr) * 32 + fq * 8);   // 16 KB of weights, L2-resident: straight to registers
+        wl[i] = *(const bf16x8*)(wpk + C * 32 + (i * 16 + fr) * 32 + fq * 8);
     }
-    f32x4 bv[8];
+    float piv[8];                                       // statistics pivot: the first bias of the lane's group
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bv[i] = *(const f32x4*)(bias + 64 * (i >> 2) + 16 * fq + 4 * (i & 3));
+    for (int i = 0; i < 8; ++i) piv[i] = bias[64 * (i >> 2) + 16 * fq + 4 * (i & 3)];
     float gs[8], gss[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) gs[i] = gss[i] = 0.f;
     int cnt = 0;
+    __syncthreads();
     // wave w: tile rows 2w, 2w+1 (128 pixels = 8 pixel tiles).  In the accumulator layout neighbouring lanes are
-    // neighbouring PIXELS (256 B apart in the 16-bit output), so 16-bit outputs are transposed through LDS -- the wave's own,
-    // already consumed, 8 KB of im2col rows -- and leave as 1 KB contiguous per store (4 pixels x 128 channels).
+    // neighbouring PIXELS (256 B apart in the 16-bit output), so 16-bit outputs are transposed through the wave's 4 KB of
+    // LDS and leave as 1 KB contiguous per store (4 pixels x 128 channels).  Staged rows are 256 B (128 couts x 2 B) with
+    // the 16-B chunk index XOR-ed with the pixel (accumulator-layout writes touch 16 rows per access).
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-    // Staging area = the first 4 KB of the wave's own 8 KB of im2col rows, i.e. the rows of pixel tiles 0..3, free once
-    // their fragments are in registers; the fragments are read four tiles at a time.  Staged rows are 256 B (128 couts x 2 B)
-    // with the 16-B chunk index XOR-ed with the pixel (accumulator-layout writes touch 16 rows per access).
-    char* const stg = xs + wave * (128 * 64);
-    bf16x8 xfa[4];
-#pragma unroll 4
+    char* const stg = stgbuf + wave * 4096;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
     for (int t = 0; t < 8; ++t) {
-        if ((t & 3) == 0) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int pu = wave * 128 + (t + u) * 16 + fr;
-                xfa[u] = *(const bf16x8*)(xs + pu * 64 + ((fq ^ (((pu >> 2) & 1) << 1)) << 4));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (before the staging below overwrites tiles 0..3)
-        }
-        const bf16x8 xft = (t & 3) == 0 ? xfa[0] : ((t & 3) == 1 ? xfa[1] : ((t & 3) == 2 ? xfa[2] : xfa[3]));
         const int p = wave * 128 + t * 16 + fr;                       // this lane's pixel in the tile
+        const char* pb = (const char*)sin + ((p >> 6) * RW + (p & 63)) * 4;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = *(const float*)(pb + offb[r]);
+        if (fq == 3) { v[3] = v[4] = v[5] = 1.f; v[6] = v[7] = 0.f; }  // k = 27..29: the bias slots; 30, 31 unused
+        bf16x8 xh, xl;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            xh[r] = (bf16_t)v[r];
+            xl[r] = (bf16_t)(v[r] - (float)xh[r]);
+        }
         const int y = y0 + (p >> 6), xx = x0 + (p & 63);
         const bool ok = y < H && xx < W;
         const long long o = (((long long)b * H + y) * W + xx) * C + 16 * fq;
         f32x4 acc[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xft, bv[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh, zero4, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh, acc[i], 0, 0, 0);
         if (ok && o32) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
@@ -249,9 +245,9 @@ __global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __res
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int px = q * 4 + (lane >> 4), ch = lane & 15;
-                const u32x4 v = *(const u32x4*)(stg + px * 256 + ((ch ^ px) << 4));
+                const u32x4 v4 = *(const u32x4*)(stg + px * 256 + ((ch ^ px) << 4));
                 if (ty < H && tx + px < W)
-                    *(u32x4*)(outp + ((((long long)b * H + ty) * W + tx + px) * C) * 2 + ch * 16) = v;
+                    *(u32x4*)(outp + ((((long long)b * H + ty) * W + tx + px) * C) * 2 + ch * 16) = v4;
             }
             asm volatile("" ::: "memory");
         }
@@ -259,13 +255,14 @@ __global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __res
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = acc[i][r] - bv[i][0]; gs[i] += d; gss[i] = fmaf(d, d, gss[i]); }
+                for (int r = 0; r < 4; ++r) { const float d = acc[i][r] - piv[i]; gs[i] += d; gss[i] = fmaf(d, d, gss[i]); }
             ++cnt;
         }
     }
     if (gn_partial) {
         // 32 GroupNorm groups of 4 couts: group of (half h, fq, tile i) = 16*h + 4*fq + i.  Sums are relative to the
         // group's first bias (E[x] ~ 0 makes that a good pivot); merge the 16 pixel columns, then the 4 waves.
+        __syncthreads();                                              // every wave has read its last halo values
         const float n = vt_row16_sum(4.0f * (float)cnt);              // 16-lane DPP row sums (vt_common.h)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -273,7 +270,7 @@ __global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __res
             if (fr == 0) {
                 const int g = 16 * (i >> 2) + 4 * fq + (i & 3);
                 const float ms = n > 0.f ? s1 / n : 0.f;
-                red[wave][g][0] = n; red[wave][g][1] = bv[i][0] + ms; red[wave][g][2] = n > 0.f ? fmaxf(s2 - s1 * ms, 0.f) : 0.f;
+                red[wave][g][0] = n; red[wave][g][1] = piv[i] + ms; red[wave][g][2] = n > 0.f ? fmaxf(s2 - s1 * ms, 0.f) : 0.f;
             }
         }
         __syncthreads();
