@@ -134,19 +134,26 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 // the first layer's rounding was 5 % of the whole encoder's latent error).  K slots 27..29 carry the bias the same way
 // (operand 1.0 x three bf16 pieces of the bias), so accumulators start at zero.  The kernel is bound by its output write.
 // Workgroup = 4 waves, 8 rows x 64 pixels x 128 couts; LDS: fp32 halo 3 x 10 x 66 (reused for the statistics) + 4 KB of
-// store staging per wave = 24 KB.  A lane builds its operand fragment (8 k-values of one pixel) straight from the halo:
+// store staging per wave + the 8 KB of lo weights = 32 KB.  A lane builds its operand fragment (8 k-values of one pixel) straight from the halo:
 // 8 ds_read_b32 at per-lane tap offsets.  The 16 KB of weights go from L2 to registers.  Weight rows use the interleaved
 // cout map: lane (fq, fr) holds couts 64*h + 16*fq + 4*i + r of pixel fr (tile i of half h), i.e. 16 consecutive couts
 // per half -> 32-B fp16 / 64-B fp32 pieces.
 // wpk: [2 (hi, lo)][128 rows][32 k] bf16 in that row order, k = ci*9 + ky*3 + kx; hi rows carry the bias in k = 27..29.
 constexpr int CM_ROWS = 8, CM_PIX = 64;
-__global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wpk,
+#ifndef CONV_IN_OCC
+#define CONV_IN_OCC 3
+#endif
+#ifndef CONV_IN_UNROLL
+#define CONV_IN_UNROLL 1
+#endif
+__global__ __launch_bounds__(256, CONV_IN_OCC) void conv_in_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ o32,
                                                            bf16_t* __restrict__ o16, f16_t* __restrict__ oh,
                                                            float* __restrict__ gn_partial, int H, int W) {
     constexpr int RW = CM_PIX + 2, RH = CM_ROWS + 2, C = 128;
     __shared__ __attribute__((aligned(16))) float sin[3 * RH * RW];
     __shared__ __attribute__((aligned(16))) char stgbuf[4 * 4096];
+    __shared__ __attribute__((aligned(16))) char wlds[128 * 64];   // the lo weight rows (64 B each, 16-B chunk ^ ((row >> 2) & 3))
     float (*red)[32][3] = (float (*)[32][3])sin;       // statistics scratch: reuses the halo once every wave is done with it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, y0 = blockIdx.y * CM_ROWS, x0 = blockIdx.x * CM_PIX;
@@ -157,6 +164,10 @@ __global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __res
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long long)b * 3 + c) * H + iy) * W + ix];
         sin[i] = v;
     }
+    for (int q = tid; q < 512; q += 256) {
+        const int row = q >> 2, ch = q & 3;
+        *(bf16x8*)(wlds + row * 64 + ((ch ^ ((row >> 2) & 3)) << 4)) = *(const bf16x8*)(wpk + C * 32 + row * 32 + ch * 8);
+    }
     const int fr = lane & 15, fq = lane >> 4;
     // byte offsets of this lane's 8 k-values (k = 8*fq + r) relative to the pixel's window origin; k >= 27 reads tap 0
     int offb[8];
@@ -166,12 +177,10 @@ __global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __res
         const int ci = kk / 9, ky = (kk - ci * 9) / 3, kx = kk - ci * 9 - ky * 3;
         offb[r] = ((ci * RH + ky) * RW + kx) * 4;
     }
-    bf16x8 wh[8], wl[8];
+    bf16x8 wh[8];                                       // hi weights (8 KB, L2-resident) live in registers, lo ones in LDS
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        wh[i] = *(const bf16x8*)(wpk + (i * 16 + fr) * 32 + fq * 8);   // 16 KB of weights, L2-resident: straight to registers
-        wl[i] = *(const bf16x8*)(wpk + C * 32 + (i * 16 + fr) * 32 + fq * 8);
-    }
+    for (int i = 0; i < 8; ++i) wh[i] = *(const bf16x8*)(wpk + (i * 16 + fr) * 32 + fq * 8);
+    const char* const wlp = wlds + fr * 64 + ((fq ^ ((fr >> 2) & 3)) << 4);
     float piv[8];                                       // statistics pivot: the first bias of the lane's group
 #pragma unroll
     for (int i = 0; i < 8; ++i) piv[i] = bias[64 * (i >> 2) + 16 * fq + 4 * (i & 3)];
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __res
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     char* const stg = stgbuf + wave * 4096;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll CONV_IN_UNROLL
     for (int t = 0; t < 8; ++t) {
         const int p = wave * 128 + t * 16 + fr;                       // this lane's pixel in the tile
         const char* pb = (const char*)sin + ((p >> 6) * RW + (p & 63)) * 4;
@@ -207,11 +216,12 @@ __global__ __launch_bounds__(256, 3) void conv_in_mfma_kernel(const float* __res
         const long long o = (((long long)b * H + y) * W + xx) * C + 16 * fq;
         f32x4 acc[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh, zero4, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl, acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl, zero4, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wlp + i * 1024), xh, acc[i], 0, 0, 0);
         if (ok && o32) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
