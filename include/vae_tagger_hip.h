@@ -109,7 +109,7 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         bf16 (read only by norm2), 0 = stored as fp32 / bf16.
  * flag 5: 1 (default) = conv_in (3 -> 128 channels) runs on the matrix cores with split (hi + lo) bf16 operands
  *         (products to ~2^-16 relative), 0 = exact fp32 VALU conv.  vt_op_conv_in follows it when Cout == 128.
- * flag 6: 1 (default) = 1x1 / GEMM launches with K <= 512 and no statistics epilogue (resnet shortcuts, attention
+ * flag 6: 1 (default) = 1x1 / GEMM launches with K <= 512 (resnet shortcuts, attention
  *         projections, Q.K^T) and the 128-cout stride-2 conv use a 192x128 tile at two workgroups per CU,
  *         0 = the 256x256 / 256x128 tiles (process-wide).
  * flag 7: mid-block attention softmax. 0 (default) = no softmax pass: Q.K^T stores exp(s - c_i) (c_i from operand norms),

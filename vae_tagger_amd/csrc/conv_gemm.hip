@@ -412,7 +412,7 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
 
 // upper bound of the pixel tiles (= GroupNorm partials per image) any configuration uses for this Cout: buffer sizing
 int vt_conv_gemm_ptiles(int HWo, int Cout) {
-    const int bp = Cout <= 32 ? 128 : (Cout <= 128 ? 192 : 256);
+    const int bp = Cout <= 32 ? 128 : 192;
     return (HWo + bp - 1) / bp;
 }
 // the pixel tiles of THIS launch
@@ -429,7 +429,7 @@ int vt_conv_gemm_col_slots(const ConvGemmArgs& a) {
     return (a.Cout + bc - 1) / bc * wc;
 }
 
-int g_gemm_short = 1;      // short-K launches without a statistics epilogue use the two-workgroups-per-CU tile (vt_set_flag 6)
+int g_gemm_short = 1;      // short-K launches use the two-workgroups-per-CU tile (vt_set_flag 6)
 void vt_conv_gemm_set_short(int on) { g_gemm_short = on != 0; }
 
 int vt_conv_gemm_config(const ConvGemmArgs& a) {
@@ -438,7 +438,7 @@ int vt_conv_gemm_config(const ConvGemmArgs& a) {
     if (a.Cout == 128 && g_gemm_short && a.ksize == 3 && a.out_mode == 0) return 9;
     if (a.Cout <= 128) return 1;
     // 1x1 / GEMM launches with K <= 512 spend most of a 256x256 tile's life in its prologue and epilogue
-    if (g_gemm_short && a.ksize == 1 && a.Cin <= 512 && !a.gn_partial && (a.Cout % 128) == 0 && a.out_mode == 0) return 9;
+    if (g_gemm_short && a.ksize == 1 && a.Cin <= 512 && (a.Cout % 128) == 0 && a.out_mode == 0) return 9;
     return 2;
 }
 const char* vt_conv_gemm_config_name(int cfg) {
