@@ -178,6 +178,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
     // whole cout tile real + only 16-bit outputs: they leave through the LDS transpose below (full 128-B lines per store)
     const bool staged = wide16 && a.out_mode == 0 && (a.out_bf16 || a.out_f16) && c0 + BC <= a.Cout;
     unsigned valid = 0;
+    const bool nomask = c0 + BC <= a.Wrows;                 // every column of this tile is a real one
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int p = p0 + wp * (BP / WP) + j * 16 + frow;
@@ -198,8 +199,9 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
                 } else if (a.row_mode == 2) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {      // exp(alpha*acc - rin) as one fma + v_exp_f32
-                        v[r] = cg + r < a.Wrows ? (float)(bf16_t)__builtin_amdgcn_exp2f(fmaf(acc[i][j][r], alpha2, -rin2)) : 0.f;
-                        racc += v[r];
+                        const float e = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], alpha2, -rin2));
+                        v[r] = (nomask || cg + r < a.Wrows) ? e : 0.f;
+                        racc += v[r];                  // (the fp32 value: like a softmax pass that normalises before rounding)
                     }
                 } else {
 #pragma unroll

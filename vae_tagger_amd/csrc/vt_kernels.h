@@ -31,7 +31,7 @@ struct ConvGemmArgs {
     // slot = column tile * WC + wave column, vt_conv_gemm_col_slots(a) of them.
     int row_mode;           // 0 off; 1 = no output, row_part = max over the slot of alpha*acc (columns >= Wrows excluded);
                             // 2 = the output is exp(alpha*acc - row_in[p]) (columns >= Wrows: 0), row_part = the slot's sum
-                            //     of the ROUNDED bf16 outputs; 3 = output rows are multiplied by row_in[p]
+                            //     of the fp32 values; 3 = output rows are multiplied by row_in[p]
     const float* row_in;    // [batch][row_bs]
     float* row_part;        // [batch][slots][row_bs]
     long long row_bs;
