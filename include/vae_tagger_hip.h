@@ -116,6 +116,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         P.V divides by the row sums; a launch group whose norm bound is too loose is flagged on the device and takes c_i
  *         = the exact row maximum from an extra, otherwise gated-off Q.K^T pass.  1 = always the exact row maximum.
  *         2 = fp16 scores, a row-softmax pass, bf16 P.
+ * flag 8: 1 (default) = a resnet block's 1x1 conv_shortcut runs inside its conv2 launch (extra K-steps on a bf16 copy of the
+ *         block input): no shortcut tensor is written or read back.  0 = separate GEMM launch + residual add.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

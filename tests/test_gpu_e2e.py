@@ -61,10 +61,11 @@ def test_encoder_matches_oracle_on_odd_shapes(vae, h, w):
 
 
 @pytest.mark.parametrize("flags", [(0, 0, 0, 1, 1, 1), (1, 0, 0, 1, 1, 0), (1, 1, 0, 1, 1, 1), (1, 1, 1, 1, 0, 1), (1, 1, 0, 0, 0, 0), (1, 1, 0, 1, 0, 1),
-                                   (1, 1, 0, 2, 1, 1), (1, 1, 0, 3, 1, 1), (1, 0, 0, 3, 0, 0), (1, 1, 0, 3, 1, 1, 0, 1), (1, 1, 0, 3, 1, 1, 1, 2)])
+                                   (1, 1, 0, 2, 1, 1), (1, 1, 0, 3, 1, 1), (1, 0, 0, 3, 0, 0), (1, 1, 0, 3, 1, 1, 0, 1), (1, 1, 0, 3, 1, 1, 1, 2),
+                                   (1, 1, 0, 3, 1, 1, 1, 0, 0), (1, 1, 0, 0, 1, 1, 1, 0, 1), (1, 1, 0, 1, 0, 1, 1, 0, 1)])
 def test_encoder_kernel_variants_agree(vae, flags):
     """flags: (halo conv kernel, epilogue GroupNorm statistics, fused apply, 2-workgroup tile mode 0..3, fp16 residual storage, MFMA conv_in
-    [, short-K GEMM tile, attention softmax mode 0..2]):
+    [, short-K GEMM tile, attention softmax mode 0..2, conv_shortcut fused into conv2]):
     every combination stays within the bf16 tolerance of the fp32 oracle."""
     sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
     x = synth.synth_images(2, 96, 160, seed=17)
@@ -75,7 +76,7 @@ def test_encoder_kernel_variants_agree(vae, flags):
             ctx.call("vt_set_flag", f, v)
         lat = vae.encode(x.cuda()).cpu()
     finally:
-        for f, v in enumerate((1, 1, 0, 3, 1, 1, 1, 0)):
+        for f, v in enumerate((1, 1, 0, 3, 1, 1, 1, 0, 1)):
             ctx.call("vt_set_flag", f, v)
     assert (lat - ref).abs().max().item() <= TOL_LATENT_BF16
 

@@ -24,7 +24,11 @@ struct HostTensor {
 
 struct ConvW { const bf16_t* w = nullptr; const bf16_t* wp = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0; };   // w: [cout][tap][cin]; wp: halo-kernel packing
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
-struct ResnetW { NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
+struct ResnetW {
+    NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0;
+    // conv_shortcut fused into conv2's launch (Conv3x3Args::scW): [cin/32][cout][32] bf16, interleaved cout rows; bias c2 + sc
+    const bf16_t* sc_wp = nullptr; const float* b_c2sc = nullptr;
+};
 struct AttnW { NormW gn; const bf16_t *wqk = nullptr, *wv = nullptr, *wo = nullptr; const float *bqk = nullptr, *bv = nullptr, *bo = nullptr; int c = 0; };
 struct StageW { std::vector<ResnetW> res; bool has_down = false; ConvW down; };
 
@@ -82,6 +86,7 @@ struct vt_context {
     int fuse_gn_apply = 0;          // vt_set_flag(ctx, 2, v): break-even on MI355X today, off by default
     int res_fp16 = 1;               // vt_set_flag(ctx, 4, v): residual stream stored as fp16 (math stays fp32)
     int attn_mode = 0;              // vt_set_flag(ctx, 7, v): see run_attention
+    int fuse_shortcut = 1;          // vt_set_flag(ctx, 8, v): resnet conv_shortcut inside conv2's launch
     // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
     int* rs_host = nullptr; size_t rs_host_ints = 0; hipEvent_t rs_event = nullptr;
     int conv_in_mfma = 1;           // vt_set_flag(ctx, 5, v): conv_in on the matrix cores (bf16 im2col), else exact fp32 VALU
@@ -176,6 +181,20 @@ int get_resnet(vt_context* c, const std::string& p, int cin, int cout, ResnetW* 
     if ((e = get_conv(c, p + ".conv2", cout, cout, 3, &r->c2))) return e;
     r->has_sc = cin != cout;
     if (r->has_sc && (e = get_conv(c, p + ".conv_shortcut", cout, cin, 1, &r->sc))) return e;
+    if (r->has_sc && r->c2.wp && (cin % 32) == 0) {
+        const HostTensor* w = c->find(p + ".conv_shortcut.weight");
+        const HostTensor* bs = c->find(p + ".conv_shortcut.bias");
+        const HostTensor* b2 = c->find(p + ".conv2.bias");
+        std::vector<uint16_t> hp((size_t)cin * cout);
+        for (int o = 0; o < cout; ++o)
+            for (int i = 0; i < cin; ++i)
+                hp[((size_t)(i >> 5) * cout + ((o & ~63) + vt_halo_row_of_cout(o & 63))) * 32 + (i & 31)] = f2bf(w->v[(size_t)o * cin + i]);
+        std::vector<float> bb(cout);
+        for (int o = 0; o < cout; ++o) bb[o] = b2->v[o] + bs->v[o];
+        r->sc_wp = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
+        r->b_c2sc = (const float*)c->upload(bb.data(), bb.size() * 4);
+        if (!r->sc_wp || !r->b_c2sc) return c->fail(VT_ERR_HIP, "upload failed for %s.conv_shortcut", p.c_str());
+    }
     return VT_OK;
 }
 int get_linear_bf16(vt_context* c, const std::string& name, int out, int in, std::vector<uint16_t>* w, std::vector<float>* b) {
@@ -235,7 +254,7 @@ hipError_t launch_halo(vt_context* c, const Conv3x3Args& a, hipStream_t s) {
     vt_context::ProfRec r;
     r.e0 = c->next_event(); r.e1 = c->next_event();
     if (!r.e0 || !r.e1) return hipErrorOutOfMemory;
-    r.flops = 2.0 * a.batch * (double)a.H * a.W * a.Cout * 9.0 * a.Cin;
+    r.flops = 2.0 * a.batch * (double)a.H * a.W * a.Cout * (9.0 * a.Cin + (a.scX ? a.scCin : 0));
     r.cfg = vt_conv3x3_halo_config(a);
     hipError_t e = hipEventRecord(r.e0, s);
     if (e != hipSuccess) return e;
@@ -281,9 +300,11 @@ int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int
 // `xnorm_f32` / `ss`: when ss is given the conv input is silu(x*scale + shift) with x = xnorm_f32 (fp32) or x (bf16),
 // fused into the halo staging (only valid when norm_conv_fusable()).
 // `res` / `oh` are the residual-stream tensors (input to add, output to write): fp32 when rdt == 1, fp16 when rdt == 2.
+// `sc`: a 1x1 conv of sc->x fused into the halo launch (resnet conv_shortcut); then `res` must be null.
+struct ScFuse { const bf16_t* x; const bf16_t* wp; const float* bias; int cin; };
 int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int Win, int stride, int pad, int Hout,
              int Wout, const void* res, void* oh, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32,
-             const float* xnorm_f32 = nullptr, const float* ss = nullptr, int rdt = 1) {
+             const float* xnorm_f32 = nullptr, const float* ss = nullptr, int rdt = 1, const ScFuse* sc = nullptr) {
     const float* res32 = rdt == 1 ? (const float*)res : nullptr;
     const f16_t* res16 = rdt == 2 ? (const f16_t*)res : nullptr;
     float* o32 = rdt == 1 ? (float*)oh : nullptr;
@@ -296,11 +317,12 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
         h.X = xnorm_f32 ? nullptr : x; h.Xf32 = xnorm_f32; h.scale_shift = ss;
         h.Wp = w.wp; h.bias = w.b; h.res = res32; h.res_f16 = res16; h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
+        if (sc) { h.scX = sc->x; h.scW = sc->wp; h.scCin = sc->cin; h.bias = sc->bias; }
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout, ss != nullptr); }
         HIPCK(c, launch_halo(c, h, s), "conv3x3_halo");
         return VT_OK;
     }
-    if (ss) return c->fail(VT_ERR_STATE, "internal: fused norm requested for a conv the halo kernel cannot run");
+    if (ss || sc) return c->fail(VT_ERR_STATE, "internal: fused norm / shortcut requested for a conv the halo kernel cannot run");
     ConvGemmArgs a{};
     a.X = x; a.W = w.w; a.bias = w.b; a.res = res32; a.res_f16 = res16; a.out_f32 = o32; a.out_f16 = oh16; a.out_bf16 = o16; a.zeros = c->zeros;
     a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cin = w.cin; a.Cout = w.cout; a.Wrows = w.cout;
@@ -325,12 +347,13 @@ bool norm_conv_fusable(const vt_context* c, const ConvW& w, int cin) {
 // x: the tensor to normalise (xdt 0 = bf16 conv output, 1 = fp32 / 2 = fp16 residual stream); res / oh: residual in / out (rdt).
 int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, int xdt, int B, int H, int W,
                   int groups, bf16_t* act, const void* res, void* oh, bf16_t* o16, GnState& gn, bool want_stats,
-                  hipStream_t s, int rdt) {
+                  hipStream_t s, int rdt, const ScFuse* sc = nullptr) {
     if (xdt == 2 || !norm_conv_fusable(c, w, n.c)) {          // (the fused staging reads fp32 or bf16 only)
         int r = run_gn(c, x, xdt, B, H * W, n, groups, 1, act, gn, s);
         if (r) return r;
-        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt);
+        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt, sc);
     }
+    if (sc) return c->fail(VT_ERR_STATE, "internal: fused shortcut with the fused-norm staging");
     int parts = gn.parts;
     if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, xdt, B, H * W, n.c, groups, gn.partial, &parts, s), "gn_stats");
     gn.parts = 0;
@@ -712,14 +735,23 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
         gn.parts = fuse0 ? parts : 0;
     }
 
+    auto fuse_sc = [&](const ResnetW& rw) { return c->fuse_shortcut && rw.sc_wp && c->use_halo_conv && rw.c2.wp && !c->fuse_gn_apply; };
     // one ResnetBlock2D: h <- conv2(silu(gn(conv1(silu(gn(h)))))) + shortcut(h)
     auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out) -> int {
         const int nxt = (cur + 1) % 3, scb = (cur + 2) % 3;
         const void* res = f32[cur];
         int rr;
+        ScFuse scf{h16_for_shortcut, rw.sc_wp, rw.b_c2sc, rw.cin};
+        const ScFuse* sc = nullptr;
         if (rw.has_sc) {
-            if ((rr = run_conv(c, rw.sc, h16_for_shortcut, B, h, w, 1, 0, h, w, nullptr, f32[scb], nullptr, s, nullptr, 32, nullptr, nullptr, rdt))) return rr;
-            res = f32[scb];
+            if (fuse_sc(rw)) {
+                // conv_shortcut rides in conv2's launch (extra K-steps on the bf16 copy of the block input, which the
+                // downsample conv left in f32[scb]): no shortcut tensor is written or read back
+                sc = &scf; res = nullptr;
+            } else {
+                if ((rr = run_conv(c, rw.sc, h16_for_shortcut, B, h, w, 1, 0, h, w, nullptr, f32[scb], nullptr, s, nullptr, 32, nullptr, nullptr, rdt))) return rr;
+                res = f32[scb];
+            }
         }
         // conv1's output is only ever read by norm2: with the fp16 storage mode it is kept as fp16 too (11 significand
         // bits instead of bf16's 8 at the same 2 B: one of the three 8-bit roundings per resnet block disappears)
@@ -729,9 +761,9 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
                                 c1h ? nullptr : tmid, gn, true, s, rdt))) return rr;
         if (want_bf16_out) {
             // the only consumer is the downsample conv (bf16 operand, no norm): skip the fp32 copy of h and the stats
-            return run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt);
+            return run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt, sc);
         }
-        if ((rr = run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, f32[nxt], nullptr, gn, true, s, rdt))) return rr;
+        if ((rr = run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, f32[nxt], nullptr, gn, true, s, rdt, sc))) return rr;
         cur = nxt;
         return VT_OK;
     };
@@ -750,9 +782,12 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             const int ho = h / 2, wo = w / 2;
             const int nxt = (cur + 1) % 3;
             const bool next_has_sc = (i + 1 < e.stages.size()) && e.stages[i + 1].res[0].has_sc;
-            if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], next_has_sc ? tmid : nullptr, s, &gn, e.groups, nullptr, nullptr, rdt))) return r;
-            // the bf16 copy lives in tmid until the next resnet's conv1 overwrites it; the shortcut conv runs first
-            h16 = next_has_sc ? tmid : nullptr;
+            // the bf16 copy of the new h for the next block's shortcut: in tmid when a separate shortcut conv consumes it
+            // before conv1 overwrites tmid; when the shortcut is fused into conv2 it must outlive conv1, so it goes to the
+            // third rotating buffer (the block's `scb`, free now that no shortcut tensor is written)
+            bf16_t* copy = !next_has_sc ? nullptr : (fuse_sc(e.stages[i + 1].res[0]) ? (bf16_t*)f32[(nxt + 2) % 3] : tmid);
+            if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], copy, s, &gn, e.groups, nullptr, nullptr, rdt))) return r;
+            h16 = copy;
             cur = nxt; h = ho; w = wo;
         }
     }
@@ -940,6 +975,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 4) { c->res_fp16 = value != 0; return VT_OK; }
     if (flag == 5) { c->conv_in_mfma = value != 0; return VT_OK; }
     if (flag == 6) { vt_conv_gemm_set_short(value); return VT_OK; }         // process-wide: GEMM tile choice
+    if (flag == 8) { c->fuse_shortcut = value != 0; return VT_OK; }
     if (flag == 7) {
         if (value < 0 || value > 2) return c->fail(VT_ERR_INVALID, "vt_set_flag(7): value %d not in 0..2", value);
         c->attn_mode = value;

@@ -487,6 +487,61 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     };
     for (int chunk = 0; chunk + 1 < nchunk; ++chunk) do_chunk(chunk, std::false_type{});
     do_chunk(nchunk - 1, std::true_type{});
+    if constexpr (XT == 0 && TPW == 8) {                 // (the 128-VGPR tile has no registers to spare: the launcher avoids it)
+        if (a.scX) {
+            // ---- fused 1x1 shortcut: acc += scW . scX at the centre tap, scCin / 32 plain (un-pipelined) K-steps.  A block
+            // whose channel count changes used to pay a separate GEMM launch writing shortcut(x) and this epilogue reading
+            // it back as the residual; here the ~2 us of exposed DMA latency per step run beside the other workgroup's MFMAs.
+            const bf16_t* Xs = a.scX + (long long)b * a.H * a.W * a.scCin;
+            const int scn = a.scCin >> 5;
+#pragma nounroll
+            for (int c = 0; c < scn; ++c) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads have returned ...
+                __builtin_amdgcn_s_barrier();                        // ... and everybody else's: the buffers are free
+                asm volatile("" ::: "memory");
+                {
+                    int hy = opaque(hy0), hx = hx0, hr = hr0;
+#pragma nounroll
+                    for (int j = 0; j < NXW; ++j) {
+                        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+                        const bool v = hr < HROWS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                        const void* src = v ? (const void*)(Xs + ((iy * a.W + ix) * a.scCin + dchunk * 8 + c * 32)) : a.zeros;
+                        __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(xbase + (j * NLD + wave) * 1024), 16, 0, 0);
+                        hr += NLD * 16;
+                        hx += (NLD * 16) % HWID; hy += (NLD * 16) / HWID;
+                        if (hx >= HWID) { hx -= HWID; ++hy; }
+                    }
+                    const bf16_t* wt = a.scW + (long long)c * wstep + opaque(wsrc0);
+#pragma unroll
+                    for (int j = 0; j < WPW; ++j)
+                        if (WPCS % NLD == 0 || j * NLD + wave < WPCS)
+                            __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(wt + j * NLD * 16 * 32), VT_LDS_PTR(wbase + (j * NLD + wave) * 1024), 16, 0, 0);
+                }
+                wait_vmcnt(0);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const char* ws = wbase + opaque(wfoff);
+                bf16x8 wf[TC];
+#pragma unroll
+                for (int i = 0; i < TC; ++i) wf[i] = *(const bf16x8*)(ws + i * 16 * HB);
+#pragma unroll
+                for (int jh = 0; jh < TP; jh += 4) {
+                    bf16x8 xf[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int rel = (jh + j + 1) * HWID + 1;              // centre tap
+                        xf[j] = *(const bf16x8*)(xbase + xaddr(rel & 7) + rel * HB);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < TC; ++i)
+                            acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][jh + j], 0, 0, 0);
+                }
+            }
+        }
+    }
     STAMP(3);
 #ifdef HALO_STAMP
     asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[TC - 1][TP - 1]));      // the last MFMA results have landed
@@ -641,6 +696,8 @@ hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
     if (!vt_conv3x3_halo_supported(a.Cin, a.Cout) || a.batch <= 0 || a.H <= 0 || a.W <= 0) return hipErrorInvalidValue;
     if (a.gn_partial && a.gn_cpg != 4 && a.gn_cpg != 8 && a.gn_cpg != 16) return hipErrorInvalidValue;
     if ((long long)a.H * a.W * a.Cin >= (1LL << 31)) return hipErrorInvalidValue;        // 32-bit per-image offsets
+    if ((a.scX != nullptr) != (a.scW != nullptr)) return hipErrorInvalidValue;
+    if (a.scX && (a.scCin <= 0 || (a.scCin % 32) || a.scale_shift || (long long)a.H * a.W * a.scCin >= (1LL << 31))) return hipErrorInvalidValue;
     if ((long long)(a.Cin / 32) * 9 * a.Cout * 32 >= (1LL << 31)) return hipErrorInvalidValue;
     // input mode: raw bf16 (X), or GroupNorm+SiLU fused into the staging of an fp32 (Xf32) / bf16 (X) tensor
     const int xt = a.scale_shift ? (a.Xf32 ? 1 : 2) : 0;
@@ -648,7 +705,7 @@ hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
     const bool big = (a.Cout % 256) == 0;                   // 16x16 px x 256 couts, else 32x16 px x 128 couts
     if (xt == 0) {
         if (g_halo_occ2 == 3 || (g_halo_occ2 == 2 && !big)) return launch<2, 2, 0, 8, 4>(a, s);   // 4 waves, 2 workgroups / CU
-        if (g_halo_occ2 && !big) return launch<4, 2, 0, 4, 4>(a, s);           // 16x16 px x 128 couts, 2 workgroups / CU
+        if (g_halo_occ2 && !big && !a.scX) return launch<4, 2, 0, 4, 4>(a, s);           // 16x16 px x 128 couts, 2 workgroups / CU
         return big ? launch<2, 4, 0, 8>(a, s) : launch<4, 2, 0, 8>(a, s);
     }
     if (xt == 1) return big ? launch<2, 4, 1, 8>(a, s) : launch<4, 2, 1, 8>(a, s);

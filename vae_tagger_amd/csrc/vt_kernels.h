@@ -65,6 +65,11 @@ struct Conv3x3Args {
     float* gn_partial;      // optional [batch][tiles][Cout/gn_cpg][3] (n, mean, M2) of the output values
     int gn_cpg;             // channels per GroupNorm group of the OUTPUT (4, 8 or 16)
     int batch, H, W, Cin, Cout;
+    // optional fused 1x1 conv (a resnet block's conv_shortcut): out += scW . scX at the centre tap, as scCin / 32 extra
+    // K-steps after the 3x3 loop (raw bf16 input only; its bias is expected inside `bias`)
+    const bf16_t* scX;      // NHWC bf16 [batch][H][W][scCin]
+    const bf16_t* scW;      // packed [scCin/32][Cout][32] bf16, rows in the interleaved cout order
+    int scCin;
 };
 int vt_conv3x3_halo_tiles(int H, int W, int Cout, int fused_norm);   // GroupNorm partials per image the epilogue writes
 int vt_conv_gemm_ptiles(int HWo, int Cout);        // upper bound over configurations (buffer sizing)
