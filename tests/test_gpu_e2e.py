@@ -214,20 +214,23 @@ def test_mid_attention_without_softmax_pass(gain, S):
     ref = o @ bf(sd[A + "to_out.0.weight"]).t() + sd[A + "to_out.0.bias"] + res
     ws = torch.empty(ctx.lib.vt_op_attention_workspace_bytes(B, S, C), dtype=torch.uint8, device="cuda")
     xd, rd = x.cuda(), res.cuda()
-    outs = []
     try:
-        for mode in (0, 1, 2):
-            ctx.call("vt_set_flag", 7, mode)
-            out = torch.full((B, S, C), float("nan"), device="cuda")
-            ctx.call("vt_op_attention", vp(xd), vp(rd), vp(out), B, S, C, vp(ws), ctypes.c_void_p(0))
-            torch.cuda.synchronize()
-            outs.append(out.cpu())
+        for qk in (1, 0):                                           # dedicated Q.K^T kernel / generic GEMM with the exp epilogue
+            ctx.call("vt_set_flag", 9, qk)
+            outs = []
+            for mode in (0, 1, 2):
+                ctx.call("vt_set_flag", 7, mode)
+                out = torch.full((B, S, C), float("nan"), device="cuda")
+                ctx.call("vt_op_attention", vp(xd), vp(rd), vp(out), B, S, C, vp(ws), ctypes.c_void_p(0))
+                torch.cuda.synchronize()
+                outs.append(out.cpu())
+            for out in outs:
+                assert (out - ref).abs().max().item() <= 2e-2       # bf16 P and o: ~4e-3 relative on |o| <= max|v|
+            assert (outs[0] - outs[1]).abs().max().item() <= 1e-2
+            assert torch.equal(outs[0], outs[1]) == (gain > 1)      # flagged <=> the exact-maximum path ran
     finally:
         ctx.call("vt_set_flag", 7, 0)
-    for out in outs:
-        assert (out - ref).abs().max().item() <= 2e-2           # bf16 P and o: ~4e-3 relative on |o| <= max|v|
-    assert (outs[0] - outs[1]).abs().max().item() <= 1e-2
-    assert torch.equal(outs[0], outs[1]) == (gain > 1)          # flagged <=> the exact-maximum path ran
+        ctx.call("vt_set_flag", 9, 1)
 
 
 def test_evaluation_caller_matches_oracle(vae, tmp_path):

@@ -1,0 +1,200 @@
+// Q.K^T of the VAE mid-block attention (1 head, d = 512) with the softmax numerators in the epilogue.
+//
+// The generic GEMM streams BOTH operands through LDS on every K-step and, at K = 512, spends most of a tile's life in
+// its load -> compute -> epilogue chain (0.62 PF).  Here the roles are fixed instead:
+//   * a workgroup owns 256 query rows for a whole sweep over the keys; each of its 8 waves keeps its 32 rows x 512 of Q in
+//     REGISTERS (128 VGPRs: the MFMA B operands of all 16 k-steps), loaded once;
+//   * keys stream through LDS in tiles of 64 rows x 512 (64 KB, two buffers, LDS-DMA, one barrier per tile); every wave
+//     reads the whole tile as A operands: 16.8 MFLOP per 64 KB filled, 5x the generic tile's ratio;
+//   * a wave owns complete rows of the score matrix, so row sums (or row maxima) accumulate in registers over the sweep:
+//     no partial buffers, no reduction kernel;
+//   * the epilogue of a key tile (one fma + v_exp_f32 per score, bf16 store of 32 B per lane and row) runs on the VALU
+//     beside the other resident wave's MFMAs.
+// mode 2: P[row][key] = exp(alpha * q.k - shift[row]) as bf16 (keys >= S: 0, up to ldp), rowval[row] = 1 / sum.
+// mode 1: no P; rowval[row] = max_key alpha * q.k (the exact shift of run_attention's flagged path).
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "vt_common.h"
+#include "vt_kernels.h"
+
+namespace {
+
+constexpr int QB = 256;        // query rows per workgroup (8 waves x 32)
+constexpr int KT = 64;         // keys per LDS tile
+constexpr int D = 512;         // head dim (= channels of the mid block)
+constexpr int KROWB = D * 2;   // bytes per key row in LDS
+constexpr int KBUF = KT * KROWB;
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 key tiles
+    if (a.gate && *a.gate != a.gate_expect) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    // an XCD gets a contiguous range of workgroups = the query tiles of one image (or a few): its L2 keeps that image's keys
+    const int qtiles = (a.S + QB - 1) / QB;
+    const int logical = vt_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = logical / qtiles, qt = logical - b * qtiles;
+    const bf16_t* qb = a.q + (long long)b * a.qk_bs;
+    const bf16_t* kb = a.k + (long long)b * a.qk_bs;
+    const int row0 = qt * QB + wave * 32;
+
+    // ---- this wave's Q slab: B operand of k-step ks for row tile j = q[row0 + 16 j + fr][32 ks + 8 fq .. +8]
+    bf16x8 qf[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = row0 + j * 16 + fr;
+        const bf16_t* src = row < a.S ? qb + (long long)row * a.ldq + fq * 8 : (const bf16_t*)a.zeros;
+        const int step = row < a.S ? 32 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) qf[j][ks] = *(const bf16x8*)(src + ks * step);
+    }
+    float rv[2];                                        // per row tile: running sum (mode 2) / maximum (mode 1)
+    float sh2[2];                                       // shift * log2(e)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = row0 + j * 16 + fr;
+        rv[j] = MODE == 1 ? -__builtin_inff() : 0.f;
+        sh2[j] = (MODE == 2 && row < a.S) ? a.rowin[(long long)b * a.row_bs + row] * 1.44269504f : 0.f;
+    }
+    const float alpha2 = a.alpha * 1.44269504f;
+
+    // ---- key tile staging: one wave-instruction = one key row (1 KB); lane l writes physical 16-B chunk l and fetches
+    // logical chunk l ^ (R & 15) (R = LDS row), so the 16 rows a fragment read touches hit 16 different chunk slots.
+    // LDS row R = 16 i + 4 q + r holds key 32 (i >> 1) + 8 q + 4 (i & 1) + r of the tile: MFMA tiles 0, 1 of lane (fq, fr)
+    // are keys 8 fq .. 8 fq + 7 and tiles 2, 3 keys 32 + 8 fq .. -- each 16-B store piece sits next to the other fq lanes'
+    // pieces, so one store instruction writes a contiguous 64-B half line per row.
+    auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int R = wave * 8 + jj;
+            const int key = kt * KT + 32 * ((R >> 5) & 1) + 8 * ((R >> 2) & 3) + 4 * ((R >> 4) & 1) + (R & 3);
+            const void* src = key < a.S ? (const void*)(kb + (long long)key * a.ldq + ((lane ^ (R & 15)) << 3)) : a.zeros;
+            __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(smem + buf * KBUF + R * KROWB), 16, 0, 0);
+        }
+    };
+    // fragment of key tile i at k-step ks: LDS row 16 i + fr, logical chunk 4 ks + fq -> physical (4 ks + fq) ^ fr.
+    // (4 ks + fq) ^ fr = ((ks & 3) ^ (fr >> 2)) << 2 | (fq ^ fr) & 3, plus (ks >> 2) << 4: four per-lane bases + immediates.
+    int kbase[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) kbase[m] = fr * KROWB + (((((m ^ (fr >> 2)) & 3) << 2) | ((fq ^ fr) & 3)) << 4);
+
+    f32x4 acc[4][2];                                    // (every tile's first k-step starts from zero: no clearing)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // P pieces of the previous tile, packed: stored right after the next tile's DMAs are issued, so that the vmcnt(0) in
+    // front of the barrier (one counter for loads and stores on this part) never waits for a store issued just before it
+    bf16x8 hold[2][2];
+    auto store_held = [&](int kt_prev) __attribute__((always_inline)) {
+        const int key0 = kt_prev * KT + 8 * fq;                // piece h of lane fq: keys key0 + 32 h .. + 7
+        const bool full = kt_prev * KT + KT <= a.S;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = row0 + j * 16 + fr;
+            if (row < a.S) {
+                bf16_t* dst = a.P + (long long)b * a.p_bs + (long long)row * a.ldp + key0;
+                if (full || key0 < a.ldp) *(bf16x8*)dst = hold[j][0];
+                if (full || key0 + 32 < a.ldp) *(bf16x8*)(dst + 32) = hold[j][1];
+            }
+        }
+    };
+    // scores of tile kt (in acc) -> running row value, packed P pieces
+    auto epilogue_t = [&](int kt, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int key0 = kt * KT + 8 * fq;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool real = FULL || key0 + 32 * (i >> 1) + 4 * (i & 1) + r < a.S;
+                    if (MODE == 1) {
+                        if (real) rv[j] = fmaxf(rv[j], acc[i][j][r] * a.alpha);
+                    } else {
+                        float e = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], alpha2, -sh2[j]));
+                        if (!real) e = 0.f;
+                        rv[j] += e;
+                        hold[j][i >> 1][(i & 1) * 4 + r] = (bf16_t)e;
+                    }
+                }
+        }
+    };
+    auto epilogue = [&](int kt) __attribute__((always_inline)) {
+        if (kt * KT + KT <= a.S) epilogue_t(kt, std::true_type{});
+        else epilogue_t(kt, std::false_type{});
+    };
+
+    // Waves w and w + 4 share a SIMD.  The first four run [MFMAs of tile kt][epilogue of kt] per barrier interval, the other
+    // four [epilogue of kt - 1][MFMAs of kt]: one wave's exp / convert / store work runs beside its partner's MFMAs instead
+    // of both leaving the barrier into the matrix pipe together and into the VALU together.
+    const bool late = (wave & 4) != 0;
+    const int nkt = (a.S + KT - 1) / KT;
+    stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's rows of tile kt have landed ...
+        __builtin_amdgcn_s_barrier();                          // ... everyone's; and everyone has READ tile kt - 1
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        if (late) {
+            if (kt > 0) { epilogue(kt - 1); if (MODE == 2) store_held(kt - 1); }
+        } else {
+            if (MODE == 2 && kt > 0) store_held(kt - 1);       // (a whole interval before the next vmcnt(0))
+        }
+        const char* ks_base = smem + (kt & 1) * KBUF;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            bf16x8 kf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kf[i] = *(const bf16x8*)(ks_base + kbase[ks & 3] + (ks >> 2) * 256 + i * 16 * KROWB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[j][ks], ks == 0 ? zero4 : acc[i][j], 0, 0, 0);
+        }
+        if (!late) epilogue(kt);
+    }
+    if (nkt > 0) {
+        if (late) epilogue(nkt - 1);
+        if (MODE == 2) store_held(nkt - 1);
+    }
+    // ---- the four fq lanes of a row hold its other keys
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float v = rv[j];
+        const float o1 = __shfl_xor(v, 16);
+        v = MODE == 1 ? fmaxf(v, o1) : v + o1;
+        const float o2 = __shfl_xor(v, 32);
+        v = MODE == 1 ? fmaxf(v, o2) : v + o2;
+        const int row = row0 + j * 16 + fr;
+        if (fq == 0 && row < a.S) a.rowout[(long long)b * a.row_bs + row] = MODE == 1 ? v : 1.f / v;
+    }
+}
+
+}  // namespace
+
+bool vt_attn_qk_supported(int S, int C) { return C == D && S > 0; }
+
+hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s) {
+    if (!a.q || !a.k || !a.rowout || !a.zeros || a.batch <= 0 || !vt_attn_qk_supported(a.S, a.C)) return hipErrorInvalidValue;
+    if (a.mode != 1 && a.mode != 2) return hipErrorInvalidValue;
+    if (a.mode == 2 && (!a.P || !a.rowin || (a.ldp % 8) || a.ldp < a.S || (a.p_bs % 8))) return hipErrorInvalidValue;
+    if ((a.ldq % 8) || (a.qk_bs % 8) || a.row_bs < a.S) return hipErrorInvalidValue;
+    if ((long long)a.S * a.ldq >= (1LL << 31)) return hipErrorInvalidValue;
+    const long long nblk = (long long)((a.S + QB - 1) / QB) * a.batch;
+    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_qk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_qk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (a.mode == 1) hipLaunchKernelGGL(attn_qk_kernel<1>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
+    else hipLaunchKernelGGL(attn_qk_kernel<2>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
+    return hipGetLastError();
+}

@@ -87,6 +87,7 @@ struct vt_context {
     int res_fp16 = 1;               // vt_set_flag(ctx, 4, v): residual stream stored as fp16 (math stays fp32)
     int attn_mode = 0;              // vt_set_flag(ctx, 7, v): see run_attention
     int fuse_shortcut = 1;          // vt_set_flag(ctx, 8, v): resnet conv_shortcut inside conv2's launch
+    int attn_qk_kernel = 1;         // vt_set_flag(ctx, 9, v): dedicated Q.K^T kernel (attn_qk.hip) instead of the generic GEMM
     // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
     int* rs_host = nullptr; size_t rs_host_ints = 0; hipEvent_t rs_event = nullptr;
     int conv_in_mfma = 1;           // vt_set_flag(ctx, 5, v): conv_in on the matrix cores (bf16 im2col), else exact fp32 VALU
@@ -446,6 +447,29 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
             a.out_f16 = sc.scores;
             HIPCK(c, launch_gemm(c, a, s), "attn scores");
             HIPCK(c, vt_launch_softmax_rows(sc.scores, 1, sc.probs, (long long)nb * S, S, ld, ld, s), "attn softmax");
+        } else if (c->attn_qk_kernel && vt_attn_qk_supported(S, C)) {
+            // the dedicated kernel (attn_qk.hip): Q rows resident in registers, keys streamed, a wave owns whole rows ->
+            // row maxima / sums accumulate in registers, no partial buffers
+            AttnQkArgs k{};
+            k.q = q; k.k = q + C; k.S = S; k.C = C; k.ldq = 2 * C; k.qk_bs = (long long)S * 2 * C;
+            k.row_bs = S; k.alpha = scale; k.batch = nb; k.zeros = c->zeros;
+            const int* gate = mode == 0 ? sc.flags + b0 / sc.group : nullptr;
+            k.mode = 1; k.rowout = shift; k.gate = gate; k.gate_expect = 1;
+            HIPCK(c, vt_launch_attn_qk(k, s), "attn row max");
+            k.mode = 2; k.P = sc.probs; k.ldp = ld; k.p_bs = (long long)S * ld; k.rowin = shift; k.rowout = rinv; k.gate = nullptr;
+            if (c->profiling) {
+                vt_context::ProfRec r;
+                r.e0 = c->next_event(); r.e1 = c->next_event();
+                if (!r.e0 || !r.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+                r.flops = 2.0 * nb * (double)S * S * C;
+                r.cfg = VT_PROF_ATTN_QK;
+                HIPCK(c, hipEventRecord(r.e0, s), "hipEventRecord");
+                HIPCK(c, vt_launch_attn_qk(k, s), "attn exp scores");
+                HIPCK(c, hipEventRecord(r.e1, s), "hipEventRecord");
+                c->prof.push_back(r);
+            } else {
+                HIPCK(c, vt_launch_attn_qk(k, s), "attn exp scores");
+            }
         } else {
             const int slots = vt_conv_gemm_col_slots(a);
             if ((size_t)slots > attn_slots_bound(S)) return c->fail(VT_ERR_WORKSPACE, "attention: %d column slots exceed the scratch", slots);
@@ -976,6 +1000,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 5) { c->conv_in_mfma = value != 0; return VT_OK; }
     if (flag == 6) { vt_conv_gemm_set_short(value); return VT_OK; }         // process-wide: GEMM tile choice
     if (flag == 8) { c->fuse_shortcut = value != 0; return VT_OK; }
+    if (flag == 9) { c->attn_qk_kernel = value != 0; return VT_OK; }
     if (flag == 7) {
         if (value < 0 || value > 2) return c->fail(VT_ERR_INVALID, "vt_set_flag(7): value %d not in 0..2", value);
         c->attn_mode = value;

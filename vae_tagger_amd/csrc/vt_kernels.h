@@ -44,10 +44,28 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s);
 // which tile configuration the dispatcher picks for these args: 0 = 128x32, 1 = 256x128, 2 = 256x256
 int vt_conv_gemm_config(const ConvGemmArgs& a);
 const char* vt_conv_gemm_config_name(int cfg);
-constexpr int VT_NUM_MFMA_CONFIGS = 10;  // 0..2 conv_gemm tiles, 3..8 conv3x3_halo <tile, XT>, 9 conv_gemm two-workgroups-per-CU tile
-constexpr int VT_PROF_GN_APPLY = 10;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES
-constexpr int VT_NUM_PROF_SLOTS = 11;
+constexpr int VT_NUM_MFMA_CONFIGS = 11;  // 0..2 conv_gemm tiles, 3..8 conv3x3_halo <tile, XT>, 9 conv_gemm two-workgroups-per-CU tile, 10 attn_qk
+constexpr int VT_PROF_ATTN_QK = 10;
+constexpr int VT_PROF_GN_APPLY = 11;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 12;
 void vt_conv_gemm_set_short(int on);     // short-K launches: two-workgroups-per-CU tile (default on)
+
+// Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
+struct AttnQkArgs {
+    const bf16_t* q; const bf16_t* k;   // row-major [S][ldq] bf16 (the q | k buffer: ldq = 2 C), batch stride qk_bs
+    int S, C, ldq; long long qk_bs;
+    bf16_t* P; int ldp; long long p_bs; // mode 2: [S][ldp] bf16 out, columns [S, ldp) written as 0
+    const float* rowin;                 // mode 2: per-row exponent shift [batch][row_bs]
+    float* rowout;                      // mode 1: row maxima of alpha q.k; mode 2: 1 / row sum   [batch][row_bs]
+    long long row_bs;
+    float alpha;
+    int mode;                           // 1 or 2
+    int batch;
+    const void* zeros;                  // >= 16 zero bytes on the device
+    const int* gate; int gate_expect;   // optional: the launch is a no-op unless *gate == gate_expect
+};
+bool vt_attn_qk_supported(int S, int C);
+hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s);
 
 // 3x3 stride-1 pad-1 conv, halo-tile kernel (conv3x3_halo.hip)
 struct Conv3x3Args {
