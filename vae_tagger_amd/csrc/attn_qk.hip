@@ -87,17 +87,24 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
 
     // P pieces of the previous tile, packed: stored right after the next tile's DMAs are issued, so that the vmcnt(0) in
     // front of the barrier (one counter for loads and stores on this part) never waits for a store issued just before it
+    // (In the accumulator layout the four pieces of a row's 64-B half line sit in lanes 16 apart, and NEIGHBOURING lanes
+    // hold different rows: stored as they stand, every lane's 16 B is its own memory request -- measured, the P write then
+    // costs as much as the MFMAs.  The epilogue therefore moves piece (fr, fq) to lane 4 fr + fq with ds_bpermute, so each
+    // quad of lanes writes 64 contiguous bytes.)
     bf16x8 hold[2][2];
+    const int sr = lane >> 2, sp = lane & 3;                   // after the permute: this lane stores row sr, piece sp
+    const int perm_addr = (sp * 16 + sr) << 2;                 // ... which it takes from lane 16 sp + sr
     auto store_held = [&](int kt_prev) __attribute__((always_inline)) {
-        const int key0 = kt_prev * KT + 8 * fq;                // piece h of lane fq: keys key0 + 32 h .. + 7
+        const int key0 = kt_prev * KT + 8 * sp;                // half h: keys key0 + 32 h .. + 7
         const bool full = kt_prev * KT + KT <= a.S;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int row = row0 + j * 16 + fr;
+            const int row = row0 + j * 16 + sr;
             if (row < a.S) {
                 bf16_t* dst = a.P + (long long)b * a.p_bs + (long long)row * a.ldp + key0;
-                if (full || key0 < a.ldp) *(bf16x8*)dst = hold[j][0];
-                if (full || key0 + 32 < a.ldp) *(bf16x8*)(dst + 32) = hold[j][1];
+                // streaming stores: 4+ GB of P per launch must not push the key tiles out of the XCD's L2
+                if (full || key0 < a.ldp) __builtin_nontemporal_store(hold[j][0], (bf16x8*)dst);
+                if (full || key0 + 32 < a.ldp) __builtin_nontemporal_store(hold[j][1], (bf16x8*)(dst + 32));
             }
         }
     };
@@ -120,6 +127,18 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
                         rv[j] += e;
                         hold[j][i >> 1][(i & 1) * 4 + r] = (bf16_t)e;
                     }
+                }
+        }
+        if (MODE == 2) {
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    i32x4 v = __builtin_bit_cast(i32x4, hold[j][h]);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) v[d] = __builtin_amdgcn_ds_bpermute(perm_addr, v[d]);
+                    hold[j][h] = __builtin_bit_cast(bf16x8, v);
                 }
         }
     };

@@ -369,26 +369,34 @@ struct AttnScratch {
     int group;
 };
 
-// Probabilities (and, on the three-pass path, scores) are materialised for `group` images at a time (one batched launch
-// each for Q.K^T and P.V): as many images as fit an 8 GiB budget (1 GiB per image at S = 16384).
-int attn_group(int B, int S) {
+// Row stride (elements) of the S x S score / probability matrices and of v^T: S rounded up to 8, plus 2112 (4 KB + 128 B) when that would
+// make the row pitch a multiple of 2 KB -- 16 rows of one store instruction (or 256 rows of one tile's K-step) at a
+// power-of-two pitch all fall on the same HBM channel (measured: the P write of attn_qk.hip cost as much as its MFMAs).
+size_t attn_pitch(int S) {
     const size_t ld = (size_t)(S + 7) / 8 * 8;
+    return (ld * 2) % 2048 == 0 ? ld + 2048 + 64 : ld;   // consecutive rows: a different 4-KB block AND a different 256-B sub-block
+}
+// Probabilities (and, on the three-pass path, scores) are materialised for `group` images at a time (one batched launch
+// each for Q.K^T and P.V): as many images as fit a 9.25 GiB budget (1.13 GiB per image at S = 16384), in equal launches.
+int attn_group(int B, int S) {
+    const size_t ld = attn_pitch(S);
     const size_t per_img = (size_t)S * ld * 4;                      // fp16 scores + bf16 probs
-    size_t g = ((size_t)8 << 30) / (per_img ? per_img : 1);
+    size_t g = ((size_t)37 << 28) / (per_img ? per_img : 1);       // 9.25 GiB: eight images at S = 16384 with the padded pitch
     if (g < 1) g = 1;
     if (g > (size_t)B) g = (size_t)B;
-    return (int)g;
+    const size_t ngroups = ((size_t)B + g - 1) / g;                // equal launches rather than a small last one
+    return (int)(((size_t)B + ngroups - 1) / ngroups);
 }
 // (row, column slot) partials per row: every tile configuration gives a wave 64 columns (the 32-column one has one slot)
 size_t attn_slots_bound(int S) { return (size_t)(S + 7) / 8 * 8 / 64 + 4; }
 size_t attn_scratch_bytes(int B, int S, int C) {
-    const size_t ld = (size_t)(S + 7) / 8 * 8, G = (size_t)attn_group(B, S);
+    const size_t ld = attn_pitch(S), G = (size_t)attn_group(B, S);
     return align_up((size_t)B * S * 2 * C * 2) + align_up((size_t)B * C * ld * 2) + align_up(G * S * ld * 2) +
            align_up(G * S * ld * 2) + align_up((size_t)B * S * C * 2) + 5 * align_up((size_t)B * S * 4) +
            align_up(G * attn_slots_bound(S) * S * 4) + align_up((size_t)B * 4);
 }
 AttnScratch carve_attn(char* p, int B, int S, int C) {
-    const size_t ld = (size_t)(S + 7) / 8 * 8, G = (size_t)attn_group(B, S);
+    const size_t ld = attn_pitch(S), G = (size_t)attn_group(B, S);
     AttnScratch a;
     a.group = (int)G;
     a.qk = (bf16_t*)p; p += align_up((size_t)B * S * 2 * C * 2);
@@ -411,7 +419,8 @@ AttnScratch carve_attn(char* p, int B, int S, int C) {
 int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* res, void* out, int B, int S,
                   const AttnScratch& sc, hipStream_t s, GnState* gn = nullptr, int groups = 32, int rdt = 1) {
     const int C = w.c;
-    const int ld = (S + 7) / 8 * 8;
+    const int ld = (S + 7) / 8 * 8;                 // K extent of P.V (columns [S, ld) of P are zero)
+    const int lp = (int)attn_pitch(S);              // row pitch of scores / P / v^T
     ConvGemmArgs a{};
     a.zeros = c->zeros; a.ksize = 1; a.stride = 1; a.pad = 0; a.Hin = a.Hout = 1; a.alpha = 1.f;
     // q | k = x Wqk^T + bqk  -> [B][S][2C]
@@ -421,8 +430,8 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
     HIPCK(c, launch_gemm(c, a, s), "attn qk proj");
     // v^T = Wv x^T + bv -> [B][C][ld]   (Wv rows are the "pixel" operand, tokens the "cout" operand)
     a.X = w.wv; a.W = x16; a.bias = w.bv; a.bias_mode = 2; a.out_bf16 = sc.vt;
-    a.Win = a.Wout = C; a.Cin = C; a.Cout = ld; a.Wrows = S; a.ldx = C; a.ldw = C; a.ldo = ld;
-    a.x_bs = 0; a.w_bs = (long long)S * C; a.o_bs = (long long)C * ld; a.batch = B;
+    a.Win = a.Wout = C; a.Cin = C; a.Cout = ld; a.Wrows = S; a.ldx = C; a.ldw = C; a.ldo = lp;
+    a.x_bs = 0; a.w_bs = (long long)S * C; a.o_bs = (long long)C * lp; a.batch = B;
     HIPCK(c, launch_gemm(c, a, s), "attn v proj");
     const float scale = 1.0f / sqrtf((float)C);
     const int mode = c->attn_mode;                  // 0: exponent shift from operand norms, exact row maximum if flagged;
@@ -437,8 +446,8 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
         const bf16_t* q = sc.qk + (long long)b0 * S * 2 * C;
         // s = q k^T / sqrt(C), [nb][S][ld]
         a.X = q; a.W = q + C; a.bias = nullptr; a.bias_mode = 0; a.out_bf16 = nullptr; a.out_f32 = nullptr; a.out_f16 = nullptr;
-        a.Win = a.Wout = S; a.Cin = C; a.Cout = ld; a.Wrows = S; a.ldx = 2 * C; a.ldw = 2 * C; a.ldo = ld;
-        a.x_bs = a.w_bs = (long long)S * 2 * C; a.o_bs = (long long)S * ld; a.batch = nb; a.alpha = scale;
+        a.Win = a.Wout = S; a.Cin = C; a.Cout = ld; a.Wrows = S; a.ldx = 2 * C; a.ldw = 2 * C; a.ldo = lp;
+        a.x_bs = a.w_bs = (long long)S * 2 * C; a.o_bs = (long long)S * lp; a.batch = nb; a.alpha = scale;
         a.row_mode = 0; a.row_in = nullptr; a.row_part = nullptr; a.row_bs = S; a.gate = nullptr; a.gate_expect = 0;
         float* shift = sc.shift + (long long)b0 * S;
         float* rinv = sc.rinv + (long long)b0 * S;
@@ -446,7 +455,7 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
             // fp16 scores (|s| is O(1): fp16's 2^-11 is far below the bf16 rounding of P), one softmax pass over them
             a.out_f16 = sc.scores;
             HIPCK(c, launch_gemm(c, a, s), "attn scores");
-            HIPCK(c, vt_launch_softmax_rows(sc.scores, 1, sc.probs, (long long)nb * S, S, ld, ld, s), "attn softmax");
+            HIPCK(c, vt_launch_softmax_rows(sc.scores, 1, sc.probs, (long long)nb * S, S, lp, lp, s), "attn softmax");
         } else if (c->attn_qk_kernel && vt_attn_qk_supported(S, C)) {
             // the dedicated kernel (attn_qk.hip): Q rows resident in registers, keys streamed, a wave owns whole rows ->
             // row maxima / sums accumulate in registers, no partial buffers
@@ -456,7 +465,7 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
             const int* gate = mode == 0 ? sc.flags + b0 / sc.group : nullptr;
             k.mode = 1; k.rowout = shift; k.gate = gate; k.gate_expect = 1;
             HIPCK(c, vt_launch_attn_qk(k, s), "attn row max");
-            k.mode = 2; k.P = sc.probs; k.ldp = ld; k.p_bs = (long long)S * ld; k.rowin = shift; k.rowout = rinv; k.gate = nullptr;
+            k.mode = 2; k.P = sc.probs; k.ldp = lp; k.p_bs = (long long)S * lp; k.rowin = shift; k.rowout = rinv; k.gate = nullptr;
             if (c->profiling) {
                 vt_context::ProfRec r;
                 r.e0 = c->next_event(); r.e1 = c->next_event();
@@ -484,9 +493,9 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
             HIPCK(c, vt_launch_attn_row_reduce(sc.part, slots, S, S, nb, 1, rinv, nullptr, 0, s), "attn row sums");
         }
         // o = P v -> bf16 [nb][S][C]   (rows of P~ scaled by 1 / row sum in the epilogue)
-        a.X = sc.probs; a.W = sc.vt + (long long)b0 * C * ld; a.out_f16 = nullptr; a.out_bf16 = sc.o + (long long)b0 * S * C;
-        a.Cin = ld; a.Cout = C; a.Wrows = C; a.ldx = ld; a.ldw = ld; a.ldo = C; a.alpha = 1.f;
-        a.x_bs = (long long)S * ld; a.w_bs = (long long)C * ld; a.o_bs = (long long)S * C;
+        a.X = sc.probs; a.W = sc.vt + (long long)b0 * C * lp; a.out_f16 = nullptr; a.out_bf16 = sc.o + (long long)b0 * S * C;
+        a.Cin = ld; a.Cout = C; a.Wrows = C; a.ldx = lp; a.ldw = lp; a.ldo = C; a.alpha = 1.f;
+        a.x_bs = (long long)S * lp; a.w_bs = (long long)C * lp; a.o_bs = (long long)S * C;
         a.row_part = nullptr; a.gate = nullptr;
         if (mode == 2) { a.row_mode = 0; a.row_in = nullptr; } else { a.row_mode = 3; a.row_in = rinv; }
         HIPCK(c, launch_gemm(c, a, s), "attn pv");
