@@ -118,6 +118,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         2 = fp16 scores, a row-softmax pass, bf16 P.
  * flag 8: 1 (default) = a resnet block's 1x1 conv_shortcut runs inside its conv2 launch (extra K-steps on a bf16 copy of the
  *         block input): no shortcut tensor is written or read back.  0 = separate GEMM launch + residual add.
+ * flag 9: 1 (default) = Q.K^T of the mid-block attention (modes 0 / 1 of flag 7, 512 channels) on its own kernel (Q rows in
+ *         registers, keys streamed through LDS, row sums in registers); 0 = the generic GEMM with the exp epilogue.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 
