@@ -157,8 +157,10 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's rows of tile kt have landed ...
         __builtin_amdgcn_s_barrier();                          // ... everyone's; and everyone has READ tile kt - 1
         asm volatile("" ::: "memory");
-        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        // An LDS-DMA piece costs its wave ~100 issue cycles: the late waves issue theirs now (beside the partner's MFMAs),
+        // the early ones after their MFMAs (beside the partner's) -- not all eight waves at once behind the barrier.
         if (late) {
+            if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
             if (kt > 0) { epilogue(kt - 1); if (MODE == 2) store_held(kt - 1); }
         } else {
             if (MODE == 2 && kt > 0) store_held(kt - 1);       // (a whole interval before the next vmcnt(0))
@@ -175,7 +177,10 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[j][ks], ks == 0 ? zero4 : acc[i][j], 0, 0, 0);
         }
-        if (!late) epilogue(kt);
+        if (!late) {
+            if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+            epilogue(kt);
+        }
     }
     if (nkt > 0) {
         if (late) epilogue(nkt - 1);
