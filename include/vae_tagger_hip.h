@@ -120,6 +120,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         block input): no shortcut tensor is written or read back.  0 = separate GEMM launch + residual add.
  * flag 9: 1 (default) = Q.K^T of the mid-block attention (modes 0 / 1 of flag 7, 512 channels) on its own kernel (Q rows in
  *         registers, keys streamed through LDS, row sums in registers); 0 = the generic GEMM with the exp epilogue.
+ * flag 10: 1 (default) = P.V reads the probabilities (4+ GB per launch, read once) with the streaming (nt) cache policy so they
+ *         do not displace the rest of the working set from L2 / Infinity Cache; 0 = default policy.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

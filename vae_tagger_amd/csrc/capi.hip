@@ -87,6 +87,7 @@ struct vt_context {
     int res_fp16 = 1;               // vt_set_flag(ctx, 4, v): residual stream stored as fp16 (math stays fp32)
     int attn_mode = 0;              // vt_set_flag(ctx, 7, v): see run_attention
     int fuse_shortcut = 1;          // vt_set_flag(ctx, 8, v): resnet conv_shortcut inside conv2's launch
+    int pv_stream = 1;              // vt_set_flag(ctx, 10, v): P.V reads P (4+ GB, read once) with the streaming cache policy
     int attn_qk_kernel = 1;         // vt_set_flag(ctx, 9, v): dedicated Q.K^T kernel (attn_qk.hip) instead of the generic GEMM
     // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
     int* rs_host = nullptr; size_t rs_host_ints = 0; hipEvent_t rs_event = nullptr;
@@ -498,7 +499,9 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
         a.x_bs = (long long)S * lp; a.w_bs = (long long)C * lp; a.o_bs = (long long)S * C;
         a.row_part = nullptr; a.gate = nullptr;
         if (mode == 2) { a.row_mode = 0; a.row_in = nullptr; } else { a.row_mode = 3; a.row_in = rinv; }
+        a.x_stream = c->pv_stream;
         HIPCK(c, launch_gemm(c, a, s), "attn pv");
+        a.x_stream = 0;
     }
     a.row_mode = 0; a.row_in = nullptr;
     // out = o Wo^T + bo + residual -> fp32 [B][S][C]
@@ -1010,6 +1013,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 6) { vt_conv_gemm_set_short(value); return VT_OK; }         // process-wide: GEMM tile choice
     if (flag == 8) { c->fuse_shortcut = value != 0; return VT_OK; }
     if (flag == 9) { c->attn_qk_kernel = value != 0; return VT_OK; }
+    if (flag == 10) { c->pv_stream = value != 0; return VT_OK; }
     if (flag == 7) {
         if (value < 0 || value > 2) return c->fail(VT_ERR_INVALID, "vt_set_flag(7): value %d not in 0..2", value);
         c->attn_mode = value;

@@ -113,7 +113,8 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
             if (XI % 8 == 0 || rblk < XI) {
                 const bool v = ((xmask[j] >> tap) & 1u) && cv;
                 const void* src = v ? (const void*)(Xb + (xoff[j] + doff + k0)) : a.zeros;
-                __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(xs + rblk * 1024), 16, 0, 0);
+                if (a.x_stream) __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(xs + rblk * 1024), 16, 0, 2);   // nt
+                else __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(xs + rblk * 1024), 16, 0, 0);
             }
         }
 #pragma unroll

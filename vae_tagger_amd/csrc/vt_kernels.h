@@ -37,6 +37,7 @@ struct ConvGemmArgs {
     long long row_bs;
     const int* gate;        // optional: the whole launch is a no-op unless *gate == gate_expect
     int gate_expect;
+    int x_stream;           // 1 = X is read once (P of P.V): its LDS-DMA carries the streaming (nt) cache policy
 };
 int vt_conv_gemm_col_slots(const ConvGemmArgs& a);
 
