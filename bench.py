@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec (6
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5, help="untimed steps first (clock ramp, code objects, allocator)")
     p.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     p.add_argument("--height", type=int, default=1024)
     p.add_argument("--width", type=int, default=1024)
