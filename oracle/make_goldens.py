@@ -98,6 +98,8 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"decoder_{name}.npz"), **out)
         print(f"decoder_{name}: logits {tuple(logits.shape)} |restatement - reference| = {err:.2e}")
 
+    input_side_goldens(ref)
+
     sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
     for name, b, h, w in ENCODER_CASES:
         x = synth.synth_images(b, h, w, seed=3)
@@ -113,5 +115,61 @@ def main():
               + " ".join(f"{k}:std={v.std():.3f},max={v.abs().max():.2f}" for k, v in taps.items()))
 
 
+class _RecordingImage:
+    """Stands in for a PIL image in SmartResize.__call__ (it only touches .size, .crop and .resize): records the crop box
+    and the resize request the REFERENCE issues, so the integer crop arithmetic is pinned without resampling anything."""
+
+    def __init__(self, size, log):
+        self.size, self.log = size, log
+
+    def crop(self, box):
+        self.log["box"] = tuple(int(v) for v in box)
+        return _RecordingImage((box[2] - box[0], box[3] - box[1]), self.log)
+
+    def resize(self, size, resample=None):
+        self.log["resize"] = (int(size[0]), int(size[1]), int(resample))
+        return self
+
+
+def input_side_goldens(ref):
+    """Integer input-side logic of the path, as the reference's own classes compute it (modules.py:142-222): the bucket list,
+    assign_bucket over a grid of image sizes (real image files: it opens them with PIL), SmartResize's centre-crop boxes."""
+    import tempfile
+    from PIL import Image
+    bk = ref.AspectRatioBucketing(512, 1024, 64)
+    buckets = np.array(bk.buckets, dtype=np.int32)
+    dims = [256, 300, 333, 384, 448, 500, 512, 576, 600, 640, 700, 720, 768, 800, 832, 896, 960, 1000, 1024, 1080, 1200, 1280,
+            1500, 1536, 1920, 2048, 3000, 4096]
+    sizes, assigned = [], []
+    with tempfile.TemporaryDirectory() as d:
+        for w in dims:
+            for h in dims:
+                f = os.path.join(d, f"{w}x{h}.png")
+                Image.new("1", (w, h)).save(f)
+                sizes.append((w, h))
+                assigned.append(bk.assign_bucket(f))
+        missing = bk.assign_bucket(os.path.join(d, "does_not_exist.png"))       # the except branch: default square bucket
+    rng = np.random.default_rng(0)
+    cases, boxes = [], []
+    targets = [tuple(b) for b in buckets[rng.choice(len(buckets), 24, replace=False)]] + [(512, 512), (1024, 1024), (192, 256)]
+    for tw, th in targets:
+        for ow, oh in [(500, 300), (300, 500), (1024, 1024), (1920, 1080), (1080, 1920), (4000, 3000), (777, 1333), (tw, th),
+                       (2 * tw, 2 * th), (tw + 1, th), (tw, th + 1)]:
+            log = {}
+            ref.SmartResize(tw, th)(_RecordingImage((ow, oh), log))
+            assert log["resize"] == (tw, th, int(Image.LANCZOS))
+            cases.append((ow, oh, tw, th))
+            boxes.append(log.get("box", (0, 0, ow, oh)))             # no crop call = the whole image
+    np.savez_compressed(os.path.join(OUT, "input_side.npz"), buckets=buckets, sizes=np.array(sizes, dtype=np.int32),
+                        assigned=np.array(assigned, dtype=np.int32), missing_default=np.array(missing, dtype=np.int32),
+                        crop_cases=np.array(cases, dtype=np.int32), crop_boxes=np.array(boxes, dtype=np.int32))
+    print(f"input_side: {len(buckets)} buckets, {len(sizes)} assign_bucket results ({len(set(assigned))} distinct), "
+          f"{len(cases)} SmartResize crop boxes")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "input_side":
+        os.makedirs(OUT, exist_ok=True)
+        input_side_goldens(import_reference())
+    else:
+        main()

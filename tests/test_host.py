@@ -67,6 +67,48 @@ def test_bucketing_matches_survey():
     assert get_vae_latent_info(1024)["latent_height"] == 128
 
 
+def test_input_side_logic_reproduces_the_reference(tmp_path):
+    """tests/golden/input_side.npz holds what the reference's own AspectRatioBucketing / SmartResize (modules.py:142-222)
+    returned in the build container (oracle/make_goldens.py input_side): bucket list, assign_bucket over 784 image sizes,
+    297 centre-crop boxes.  Integer / index work: bit-exact."""
+    import numpy as np
+    from PIL import Image
+    from oracle import resize_ref
+    from vae_tagger_amd.modules import SmartResize, smart_crop_box
+    with np.load(os.path.join(ROOT, "tests", "golden", "input_side.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    b = AspectRatioBucketing(512, 1024, 64)
+    assert np.array_equal(np.array(b.buckets, dtype=np.int32), g["buckets"])
+    got = np.array([b.bucket_for_ratio(int(w) / int(h)) for w, h in g["sizes"]], dtype=np.int32)
+    assert np.array_equal(got, g["assigned"])
+    assert len({tuple(x) for x in got}) == 67                  # SURVEY.md section 8a I3: 67 of the 81 buckets are reachable
+    for w, h in ((300, 1000), (1920, 1080), (777, 778)):      # through the file-opening entry point as well
+        f = tmp_path / f"{w}x{h}.png"
+        Image.new("1", (w, h)).save(f)
+        k = int(np.nonzero((g["sizes"] == (w, h)).all(1))[0][0]) if ((g["sizes"] == (w, h)).all(1)).any() else None
+        assert b.assign_bucket(str(f)) == (tuple(g["assigned"][k]) if k is not None else b.bucket_for_ratio(w / h))
+    assert b.assign_bucket(str(tmp_path / "missing.png")) == tuple(g["missing_default"]) == (512, 512)
+
+    class Rec:                                                 # records what SmartResize asks of the image
+        def __init__(self, size, log):
+            self.size, self.log = size, log
+
+        def crop(self, box):
+            self.log["box"] = (box[0], box[1], box[2] - box[0], box[3] - box[1])
+            return Rec((box[2] - box[0], box[3] - box[1]), self.log)
+
+        def resize(self, size, resample=None):
+            self.log["resize"] = (size, resample)
+            return self
+    for (ow, oh, tw, th), box in zip(g["crop_cases"].tolist(), g["crop_boxes"].tolist()):
+        want = (box[0], box[1], box[2] - box[0], box[3] - box[1])           # reference boxes are (l, t, r, b)
+        assert smart_crop_box(ow, oh, tw, th) == want
+        assert resize_ref.smart_crop_box(ow, oh, tw, th) == want
+        log = {}
+        SmartResize(tw, th)(Rec((ow, oh), log))
+        assert log.get("box", (0, 0, ow, oh)) == want and log["resize"] == ((tw, th), Image.LANCZOS)
+
+
 def test_shard_range_and_cost_model():
     for n in (1, 7, 16, 129):
         for world in (1, 2, 3, 8):
@@ -99,6 +141,21 @@ assert out.shape == full.shape and torch.allclose(out, full, atol=1e-6), (out - 
 lat4 = lat[:4]                                           # even split: single all-gather path
 out4 = sharding.sharded_logits(lambda x: decoder_ref.attention_decoder_forward(sd, x), lat4)
 assert torch.allclose(out4, full[:4], atol=1e-6)
+out1 = sharding.sharded_logits(lambda x: decoder_ref.attention_decoder_forward(sd, x), lat[:1])   # B < world: rank 1 holds no image
+assert out1.shape == (1, 11) and torch.allclose(out1, full[:1], atol=1e-6)
+# bucketed plan (bench.py --bucketed): whole same-shape batches placed by the cost model, ragged gather of the per-rank
+# logits -- including a step whose single batch leaves rank 1 with nothing
+rank = int(sys.argv[3])
+for batches in ([(1024, 1024, 2), (512, 512, 3), (768, 512, 1)], [(640, 640, 2)]):
+    assign, _ = sharding.assign_batches(batches, 2)
+    lats = [torch.randn(n, 16, h // 64, w // 64, generator=torch.Generator().manual_seed(w * 7 + h)) for (w, h, n) in batches]
+    outs = [decoder_ref.attention_decoder_forward(sd, lats[i]) for i in assign[rank]]
+    local = torch.cat(outs, 0) if outs else torch.empty(0, 11)
+    counts = [sum(batches[i][2] for i in assign[r]) for r in range(2)]
+    got = sharding.all_gather_logits(local, counts)
+    want = torch.cat([decoder_ref.attention_decoder_forward(sd, lats[i]) for r in range(2) for i in assign[r]], 0)
+    assert got.shape == want.shape and torch.allclose(got, want, atol=1e-6)
+    assert min(counts) == 0 or len(batches) > 1
 dist.barrier(); dist.destroy_process_group()
 print("rank", sys.argv[3], "ok")
 '''
@@ -152,7 +209,13 @@ def test_evaluation_metrics_match_scikit_learn():
     m2 = ev.compute_metrics(0.5)
     assert m2["per_class"]["t0"] == {"precision": 0.0, "recall": 0.0, "f1": 0.0, "ap": 0.0, "support": 0}
     assert m2["per_class"]["t1"]["ap"] == 1.0 and m2["per_class"]["t1"]["recall"] == 1.0
-    assert m2["mAP"] == 0.0                                  # scikit-learn raises / warns here; the reference reports 0
+    # a class without positives: scikit-learn (>= 1.2, the reference's pin) warns, scores it 0 and still averages
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for avg, key in (("macro", "mAP"), ("micro", "mAP_micro"), ("weighted", "mAP_weighted")):
+            assert abs(m2[key] - average_precision_score(yt, y_prob, average=avg)) < 1e-6, key
+    assert m2["mAP"] > 0.0
 
 
 def test_resize_tables_match_the_oracle():

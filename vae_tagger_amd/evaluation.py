@@ -80,14 +80,12 @@ class MultiLabelEvaluator:
             m[f"{name}_micro"] = float(micro)
             m[f"{name}_macro"] = float(per.mean())
             m[f"{name}_weighted"] = float((per * w).sum())
-        ap = _average_precision(y_true, y_prob)
-        has = ~np.isnan(ap)
-        if has.all():                                    # the reference reports 0.0 when a class has no positive sample
-            m["mAP"] = float(ap.mean())
-            m["mAP_micro"] = float(_average_precision(y_true.reshape(-1, 1), y_prob.reshape(-1, 1))[0])
-            m["mAP_weighted"] = float((ap * w).sum())
-        else:
-            m["mAP"] = m["mAP_micro"] = m["mAP_weighted"] = 0.0
+        # scikit-learn (what the reference calls, evaluation.py:65-67) scores a class without a positive sample as AP 0 (with a
+        # warning) and still averages: macro over all classes, weighted by support, micro over the flattened matrix
+        ap = np.nan_to_num(_average_precision(y_true, y_prob), nan=0.0)
+        m["mAP"] = float(ap.mean())
+        m["mAP_micro"] = float(np.nan_to_num(_average_precision(y_true.reshape(-1, 1), y_prob.reshape(-1, 1)), nan=0.0)[0])
+        m["mAP_weighted"] = float((ap * w).sum())
         per_class = {}
         for i in range(c):
             name = self.class_names[i] if self.class_names else f"Class_{i}"

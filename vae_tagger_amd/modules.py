@@ -133,6 +133,20 @@ def _to_normalized_tensor(img):
     return (t - 0.5) / 0.5
 
 
+def smart_crop_box(width, height, target_width, target_height, offset=lambda slack: slack // 2):
+    """(left, top, crop_w, crop_h) SmartResize cuts out of a width x height image before resizing to the target
+    (modules.py:149-178): the wider side is cropped to int(other * ratio), `offset(slack)` picks where (centre by default)."""
+    target_ratio = target_width / target_height
+    ratio = width / height
+    if ratio > target_ratio:
+        nw = int(height * target_ratio)
+        return offset(width - nw), 0, nw, height
+    if ratio < target_ratio:
+        nh = int(width / target_ratio)
+        return 0, offset(height - nh), width, nh
+    return 0, 0, width, height
+
+
 class SmartResize:
     """Centre/random/edge crop to the bucket's aspect ratio, then LANCZOS resize (modules.py:142-178)."""
 
@@ -150,16 +164,9 @@ class SmartResize:
     def __call__(self, img):
         from PIL import Image
         ow, oh = img.size
-        target_ratio = self.target_width / self.target_height
-        ratio = ow / oh
-        if ratio > target_ratio:
-            nw = int(oh * target_ratio)
-            left = self._offset(ow - nw)
-            img = img.crop((left, 0, left + nw, oh))
-        elif ratio < target_ratio:
-            nh = int(ow / target_ratio)
-            top = self._offset(oh - nh)
-            img = img.crop((0, top, ow, top + nh))
+        left, top, cw, ch = smart_crop_box(ow, oh, self.target_width, self.target_height, self._offset)
+        if (cw, ch) != (ow, oh):
+            img = img.crop((left, top, left + cw, top + ch))
         return img.resize((self.target_width, self.target_height), Image.LANCZOS)
 
 

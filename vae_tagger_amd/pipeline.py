@@ -10,7 +10,7 @@ from . import _lib
 from ._runtime import as_input, stream_ptr, vp, workspace
 from .autoencoder_kl import AutoencoderKL
 from .diffusers_vae_loader import DiffusersVAEWrapper
-from .modules import _HipDecoder
+from .modules import _HipDecoder, smart_crop_box
 
 
 class EncodeTagPipeline:
@@ -105,14 +105,7 @@ class EncodeTagPipeline:
         H, W, _ = a.shape
         if bucket is not None:
             tw, th = bucket
-            ratio, target = W / H, tw / th
-            box = (0, 0, W, H)
-            if ratio > target:
-                nw = int(H * target)
-                box = ((W - nw) // 2, 0, nw, H)
-            elif ratio < target:
-                nh = int(W / target)
-                box = (0, (H - nh) // 2, W, nh)
+            box = smart_crop_box(W, H, tw, th)
             u8 = self.resize_u8(torch.from_numpy(a.copy()), tw, th, self.FILTER_LANCZOS, box)
         else:
             u8 = self.resize_u8(torch.from_numpy(a.copy()), resolution, resolution, self.FILTER_BILINEAR)

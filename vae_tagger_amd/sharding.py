@@ -80,8 +80,13 @@ def sharded_logits(compute_logits, images, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     B = images.shape[0]
     lo, hi = shard_range(B, rank, world)
-    local = compute_logits(images[lo:hi]) if hi > lo else None
     counts = [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
-    if local is None:
-        raise ValueError("batch smaller than world size: every rank needs at least one image")
+    local = compute_logits(images[lo:hi]) if hi > lo else None
+    if B < world:
+        # some ranks hold no image (every rank knows which: B and world are global): they join the ragged gather with
+        # zero rows, and learn the tag count from the ranks that computed something -- nobody is left waiting
+        n = torch.tensor([0 if local is None else local.shape[1]], dtype=torch.int64, device=images.device)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+        if local is None:
+            local = torch.zeros(0, int(n.item()), dtype=torch.float32, device=images.device)
     return all_gather_logits(local, counts, group)
