@@ -11,8 +11,9 @@ bf16 MFMA operands / fp32 accumulate.  Weak scaling: the per-GPU batch is fixed 
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the implicit-GEMM MFMA conv):
 achieved = its algorithmic FLOPs / its summed launch durations, from HIP events recorded on the launch
-stream inside the timed region (vt_profile_begin/end in the C ABI).  `cpu_baseline` times the CPU
-oracle (oracle/, kind "port") on this box's host cores, rank 0, N=1 only, on a bounded sample.
+stream over the timed region (vt_profile_begin/end in the C ABI; ~140 event records per step -- the same K steps are run
+once more without them and reported as `ms_per_step_without_events`).  `cpu_baseline` times the CPU oracle (oracle/, kind "port") on this box's host cores,
+rank 0, N=1 only, on a bounded sample; `max_abs_dlogit` / `max_abs_dlatent` compare image 0 of the measured batch with it.
 """
 import argparse
 import ctypes
@@ -44,31 +45,79 @@ def parse():
     p.add_argument("--bucket-batch", type=int, default=8, help="images per same-shape batch in --bucketed mode")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--generic-conv", action="store_true", help="A/B: disable the halo-tile 3x3 kernel")
-    p.add_argument("--cpu-sample-res", type=int, default=1024)
     p.add_argument("--no-occ2", action="store_true", help="A/B: 128-cout convs on the one-workgroup-per-CU tile")
     p.add_argument("--lib", default=None, help="A/B: path of an alternative build of libvae_tagger_hip.so")
     p.add_argument("--flag", action="append", default=[], metavar="N=V", help="A/B: vt_set_flag(N, V) before the run (repeatable)")
     return p.parse_args()
 
 
-def cpu_baseline(res, tags, flops_target):
-    """CPU oracle (torch fp32 restatement of the reference path) on the host cores: one image."""
+def physical_cores():
+    """Physical cores of this host (unique (package, core) pairs of /proc/cpuinfo), capped by the cpuset this process may use."""
+    try:
+        pairs, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((phys, line.split(":")[1].strip()))
+        n = len(pairs)
+    except OSError:
+        n = 0
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, avail)) if n else max(1, avail)
+
+
+def cpu_baseline(x0, tags, flops_target, budget_s=85.0):
+    """CPU oracle (torch fp32 restatement of the reference path, oracle/) on this box's host cores, SURVEY.md section 8(d):
+    1 warm-up + 3 timed runs per row -- all physical cores at the benchmark shape and at 512^2, one core on a 256^2
+    sample (a single core needs minutes for a 1024^2 image) -- bounded by `budget_s`.  x0: the FIRST image of the measured
+    batch; the warm-up run's outputs are returned as the parity reference for that image.  Baseline only, never the target."""
     import torch
     from oracle import decoder_ref, encoder_ref
     from vae_tagger_amd import synth
-    cores = torch.get_num_threads()
     sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
     sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(tags), seed=1)
-    x = synth.synth_images(1, res, res, seed=0)
-    with torch.no_grad():
+    cores = physical_cores()
+    t_start = time.perf_counter()
+
+    def run(x):
+        with torch.no_grad():
+            lat = encoder_ref.vae_wrapper_encode(sd_e, x)
+            lg = decoder_ref.attention_decoder_forward(sd_d, lat)
+            decoder_ref.get_confidence(lg)
+        return lat, lg
+
+    def row(x, threads, label):
+        torch.set_num_threads(threads)
         t0 = time.perf_counter()
-        lat = encoder_ref.vae_wrapper_encode(sd_e, x)
-        decoder_ref.get_confidence(decoder_ref.attention_decoder_forward(sd_d, lat))
-        dt = time.perf_counter() - t0
-    scale = encoder_ref.encoder_flops(res, res) / flops_target
-    return {"value": round(scale / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 image {res}x{res} encode+tag, fp32 torch CPU oracle, one timed run ({dt:.1f} s)"
-                      + ("" if abs(scale - 1) < 1e-9 else f", scaled by FLOP ratio {scale:.4f} to the benchmark shape")}
+        ref = run(x)                                           # warm-up (allocator, oneDNN primitive cache)
+        warm = time.perf_counter() - t0
+        times = []
+        for _ in range(3):
+            if time.perf_counter() - t_start + warm > budget_s and times:
+                break
+            t0 = time.perf_counter()
+            run(x)
+            times.append(time.perf_counter() - t0)
+        h, w = x.shape[-2:]
+        scale = encoder_ref.encoder_flops(h, w) / flops_target
+        best = min(times)
+        return ref, {"threads": threads, "shape": f"{w}x{h}", "timed_runs": len(times), "seconds_best": round(best, 3),
+                     "seconds_mean": round(sum(times) / len(times), 3),
+                     "images_per_sec_at_bench_shape": round(scale / best, 5), "sample": label}
+
+    H, W = x0.shape[-2:]
+    ref, main_row = row(x0, cores, f"image 0 of the measured batch, {W}x{H}, encode+tag")
+    rows = [main_row]
+    if time.perf_counter() - t_start < budget_s * 0.7:
+        rows.append(row(synth.synth_images(1, 512, 512, seed=0), cores, "1 image 512x512 encode+tag, scaled by FLOP ratio")[1])
+    if time.perf_counter() - t_start < budget_s * 0.8:
+        rows.append(row(synth.synth_images(1, 256, 256, seed=0), 1, "1 image 256x256 encode+tag on ONE core, scaled by FLOP ratio")[1])
+    torch.set_num_threads(cores)
+    return ref, {"value": main_row["images_per_sec_at_bench_shape"], "unit": "images/sec", "cores": cores, "kind": "port",
+                 "sample": f"1 image {W}x{H} encode+tag, fp32 torch CPU oracle, {cores} threads = physical cores, 1 warm-up + "
+                           f"{main_row['timed_runs']} timed runs (best {main_row['seconds_best']} s)",
+                 "rows": rows, "total_seconds": round(time.perf_counter() - t_start, 1)}
 
 
 def pmc_traffic(kernel, batch, height, width):
@@ -210,6 +259,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
+    # the same K steps without the per-launch event records (the production path): reported beside the contract number
+    if a.bucketed:
+        it = iter(plan[a.warmup:])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    elapsed_plain = time.perf_counter() - t1
+    status = prof_ctx.status()
+    assert status == 0, f"vt_status = {status}: non-finite activations inside the encoder"
 
     if rank == 0:
         flops_img = pipe.flops_per_image(a.height, a.width)
@@ -233,7 +293,8 @@ def main():
             "metric": ("images/sec encode+tag, bucketed 512..1024 bf16" if a.bucketed else
                        "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_step_without_events": round(elapsed_plain / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"configs[3]: bucketed 512->1024 step 64 (67 reachable buckets), {2 * world} same-shape batches of "
                                     f"{a.bucket_batch} per step, FLUX-VAE encode + 8-head attention decoder, {a.tags} tags"
@@ -262,8 +323,21 @@ def main():
                          "avg_launch_ms": round(tot_ms[nm] / max(1, launches[nm]), 4),
                          "share_of_step": round(tot_ms[nm] / (elapsed * 1e3), 4)},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.cpu_sample_res, a.tags, flops_img)
+        if world == 1 and not a.no_cpu_baseline and not a.bucketed:
+            # parity half of the metric: image 0 of the measured batch through the HIP path (outside the timed region) against
+            # the CPU oracle's warm-up run on the same image
+            xs = x[:1]
+            if a.encode_only:
+                lat_g, lg_g = vae_model.encode(xs), None
+            else:
+                lg_g, lat_g = pipe.logits(xs, return_latent=True)
+            same = torch.equal(lg_g[0], out[0]) if lg_g is not None else torch.equal(lat_g[0], out[0])
+            (ref_lat, ref_lg), res["cpu_baseline"] = cpu_baseline(xs.cpu(), a.tags, flops_img)
+            res["max_abs_dlatent"] = float(f"{(lat_g.cpu() - ref_lat).abs().max().item():.3e}")
+            if lg_g is not None:
+                res["max_abs_dlogit"] = float(f"{(lg_g.cpu() - ref_lg).abs().max().item():.3e}")
+            res["parity"] = {"vs": "oracle/ (CPU fp32 restatement)", "image": "image 0 of the measured batch",
+                             "tolerance": 1e-2, "identical_to_the_batched_result": bool(same)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -9,7 +9,8 @@
  *   - plain C types only; every buffer is caller-owned DEVICE memory unless marked "host";
  *   - `stream` is a hipStream_t passed as void* (0 = default stream); no call synchronises the host;
  *   - every call returns VT_OK or an error code; vt_last_error(ctx) gives the message; nothing aborts;
- *   - one context per device / thread; no global state;
+ *   - one context per device / thread; no global state: every option of vt_set_flag lives in the context, every call runs on
+ *     the context's device and restores the caller's current device before it returns;
  *   - workspace is caller-provided (query the *_workspace_bytes function first), 256-B aligned.
  */
 #ifndef VAE_TAGGER_HIP_H
@@ -60,7 +61,14 @@ int vt_decoder_finalize(vt_context* ctx);
  *                         1: latent_dist.mode() = mean [B,latent,H/8,W/8]
  *                         2: mode() * scaling_factor + shift_factor -- DiffusersVAEWrapper.encode
  * vt_decode_logits   <- decoder.forward(latent), modules.py:424-468 / :333-349 -> fp32 [B,N]
- * vt_get_confidence  <- sigmoid + descending sort, modules.py:470-475 (ties: ascending tag index)
+ * vt_get_confidence  <- sigmoid + descending sort, modules.py:470-475 (ties: ascending tag index; NaN logits sort last;
+ *                       any N: up to 16384 tags in one LDS pass, more through global-memory merge passes)
+ * vt_summarize_confidence <- the per-image summary loop of infer_full.py:106-125 on the sorted outputs: per image the
+ *                       first K (confidence fp32, tag index int32; -1 / 0 beyond N) pairs and stats[4] = {number of tags with
+ *                       confidence >= threshold, max confidence, (sum of the first five) / 5, number of non-finite confidences}
+ * vt_status          sticky device-side health word of the context (SYNCHRONISES `stream`): bit 0 (VT_STATUS_NONFINITE) =
+ *                       some GroupNorm saw non-finite statistics since the last clear -- an activation left the fp16 range
+ *                       of the residual-stream storage (rerun with vt_set_flag(ctx, 4, 0)) or the weights hold inf / NaN
  * vt_encode_tag      <- the loop body of infer_full.py:101-105 for a whole batch
  */
 size_t vt_encode_workspace_bytes(const vt_context* ctx, int B, int H, int W);
@@ -71,6 +79,11 @@ int vt_decode_logits(vt_context* ctx, const float* latent_nchw, int B, int h, in
                      void* workspace, size_t workspace_bytes, void* stream);
 int vt_get_confidence(vt_context* ctx, const float* logits, int B, int N, float* conf_sorted_out,
                       int64_t* indices_out, void* stream);
+int vt_summarize_confidence(vt_context* ctx, const float* conf_sorted, const int64_t* indices, int B, int N, float threshold,
+                            int K, float* top_conf_out /* [B][K] */, int32_t* top_idx_out /* [B][K] */,
+                            float* stats_out /* [B][4] */, void* stream);
+enum { VT_STATUS_NONFINITE = 1 };
+int vt_status(vt_context* ctx, int clear, int* status_out /* host */, void* stream);
 size_t vt_encode_tag_workspace_bytes(const vt_context* ctx, int B, int H, int W);
 int vt_encode_tag(vt_context* ctx, const float* x_nchw, int B, int H, int W, float* latent_out /* may be NULL */,
                   float* logits_out, void* workspace, size_t workspace_bytes, void* stream);
@@ -101,7 +114,7 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         0 = every GroupNorm runs its own statistics pass.
  * flag 2: 1 = GroupNorm-apply + SiLU in front of a 3x3 stride-1 conv runs inside that conv's halo staging,
  *         0 (default) = as a standalone HBM-bound pass (one read + one bf16 write of the tensor).
- * flag 3: two-workgroups-per-CU tiles of the halo conv (process-wide): 3 (default) = every plain-input layer on the
+ * flag 3: two-workgroups-per-CU tiles of the halo conv: 3 (default) = every plain-input layer on the
  *         4-wave x 256-VGPR tile (16x16 px x 128 couts), 2 = only the 128-cout layers on it, 1 = the 128-cout layers on
  *         the 8-wave x 128-VGPR tile, 0 = one workgroup per CU (16x16 px x 256 couts / 32x16 px x 128 couts).
  * flag 4: 1 (default) = the residual stream between resnet blocks is STORED as fp16 (all arithmetic stays fp32;
@@ -111,7 +124,7 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         (products to ~2^-16 relative), 0 = exact fp32 VALU conv.  vt_op_conv_in follows it when Cout == 128.
  * flag 6: 1 (default) = 1x1 / GEMM launches with K <= 512 (resnet shortcuts, attention
  *         projections, Q.K^T) and the 128-cout stride-2 conv use a 192x128 tile at two workgroups per CU,
- *         0 = the 256x256 / 256x128 tiles (process-wide).
+ *         0 = the 256x256 / 256x128 tiles.
  * flag 7: mid-block attention softmax. 0 (default) = no softmax pass: Q.K^T stores exp(s - c_i) (c_i from operand norms),
  *         P.V divides by the row sums; a launch group whose norm bound is too loose is flagged on the device and takes c_i
  *         = the exact row maximum from an extra, otherwise gated-off Q.K^T pass.  1 = always the exact row maximum.

@@ -31,6 +31,8 @@ PROTOTYPES = {
     "vt_decode_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "vt_decode_logits": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "vt_get_confidence": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "vt_summarize_confidence": (_i, [_vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "vt_status": (_i, [_vp, _i, _c.POINTER(_i), _vp]),
     "vt_encode_tag_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "vt_encode_tag": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vt_preprocess_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -113,6 +115,12 @@ class Context:
 
     def call(self, name, *args):
         self.check(getattr(self.lib, name)(self.handle, *args), name)
+
+    def status(self, clear=True, stream=None):
+        """Sticky device health word (synchronises the stream): bit 0 = non-finite GroupNorm statistics were seen."""
+        v = _i(0)
+        self.call("vt_status", int(clear), ctypes.byref(v), stream if stream is not None else _vp(0))
+        return v.value
 
     def set_weight(self, name, tensor):
         """tensor: torch tensor on any device; copied to host fp32/bf16/f16 and handed over by pointer."""

@@ -101,7 +101,23 @@ class AutoencoderKL(HipModule):
             raise _lib.VTError(f"vt_encode_workspace_bytes({B},{H},{W}) = 0: unsupported shape")
         ws, ptr = workspace(x.device, need)
         ctx.call("vt_encode", vp(x), B, H, W, mode, vp(out), ctypes.c_void_p(ptr), need, stream_ptr(x.device))
+        if self.check_finite and self.status():
+            raise FloatingPointError("non-finite activations in the encoder: the fp16 residual-stream storage overflowed "
+                                     "(set_fp32_residual() stores it as fp32) or the checkpoint holds inf / NaN")
         return out
+
+    # encode() never synchronises the host, so an overflow of the fp16 residual-stream storage cannot raise from it by
+    # itself: the library keeps a sticky device-side status word instead (vt_status).  Callers check it where they
+    # synchronise anyway (the CLIs and evaluation.py do, after their .cpu()); check_finite = True makes every encode
+    # synchronise and raise.
+    check_finite = False
+
+    def status(self, clear=True):
+        dev = next(self.parameters()).device
+        return self._context().status(clear, stream_ptr(dev))
+
+    def set_fp32_residual(self, on=True):
+        self._context().call("vt_set_flag", 4, 0 if on else 1)
 
     # -- diffusers surface ---------------------------------------------------------------------------
     @torch.no_grad()

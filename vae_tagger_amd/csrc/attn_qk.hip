@@ -211,13 +211,13 @@ hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s) {
     if ((long long)a.S * a.ldq >= (1LL << 31)) return hipErrorInvalidValue;
     const long long nblk = (long long)((a.S + QB - 1) / QB) * a.batch;
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_done{0};
+    hipError_t ea = vt_once_per_device(attr_done, [&] {
         hipError_t e = hipFuncSetAttribute((const void*)attn_qk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_qk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+        return e;
+    });
+    if (ea != hipSuccess) return ea;
     if (a.mode == 1) hipLaunchKernelGGL(attn_qk_kernel<1>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
     else hipLaunchKernelGGL(attn_qk_kernel<2>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
     return hipGetLastError();

@@ -76,8 +76,10 @@ struct vt_context {
     int device = 0;
     std::string err;
     std::map<std::string, HostTensor> weights;
-    std::vector<void*> allocs;
+    std::vector<void*> enc_allocs, dec_allocs;     // packed weights, freed when the model is configured again
+    std::vector<void*>* cur_allocs = &enc_allocs;
     void* zeros = nullptr;
+    int* status = nullptr;          // device word: sticky VT_STATUS_* bits raised by kernels (vt_status reads / clears it)
     EncoderW enc;
     DecoderWeights dec;
     bool dec_configured = false, dec_finalized = false;
@@ -89,6 +91,8 @@ struct vt_context {
     int fuse_shortcut = 1;          // vt_set_flag(ctx, 8, v): resnet conv_shortcut inside conv2's launch
     int pv_stream = 1;              // vt_set_flag(ctx, 10, v): P.V reads P (4+ GB, read once) with the streaming cache policy
     int attn_qk_kernel = 1;         // vt_set_flag(ctx, 9, v): dedicated Q.K^T kernel (attn_qk.hip) instead of the generic GEMM
+    int halo_occ2 = 3;              // vt_set_flag(ctx, 3, v): two-workgroups-per-CU tile mode of the halo conv
+    int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
     // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
     int* rs_host = nullptr; size_t rs_host_ints = 0; hipEvent_t rs_event = nullptr;
     int conv_in_mfma = 1;           // vt_set_flag(ctx, 5, v): conv_in on the matrix cores (bf16 im2col), else exact fp32 VALU
@@ -120,9 +124,13 @@ struct vt_context {
     void* upload(const void* host, size_t bytes) {
         void* d = nullptr;
         if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) return nullptr;
-        allocs.push_back(d);
+        cur_allocs->push_back(d);
         if (bytes && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
         return d;
+    }
+    void free_allocs(std::vector<void*>& v) {
+        for (void* p : v) (void)hipFree(p);
+        v.clear();
     }
     const HostTensor* find(const std::string& k) const {
         auto it = weights.find(k);
@@ -131,6 +139,16 @@ struct vt_context {
 };
 
 namespace {
+
+// Every entry point that touches the GPU runs on the context's device and leaves the caller's current device as it found it.
+struct DeviceGuard {
+    int prev = -1, dev;
+    explicit DeviceGuard(const vt_context* c) : dev(c->device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
 
 #define HIPCK(ctx, e, what) do { hipError_t _e = (e); if (_e != hipSuccess) return (ctx)->hipfail(_e, what); } while (0)
 
@@ -232,7 +250,9 @@ std::vector<uint16_t> pack_conv_in_mfma(const float* w_o27, const float* bias) {
 }
 
 // ---- launch helpers -------------------------------------------------------------------------------
-hipError_t launch_gemm(vt_context* c, const ConvGemmArgs& a, hipStream_t s) {
+hipError_t launch_gemm(vt_context* c, const ConvGemmArgs& a_in, hipStream_t s) {
+    ConvGemmArgs a = a_in;
+    a.short_tiles = c->gemm_short;
     if (!c->profiling || a.gate) return vt_launch_conv_gemm(a, s);       // gated launches may be no-ops: not counted
     vt_context::ProfRec r;
     r.e0 = c->next_event(); r.e1 = c->next_event();
@@ -251,7 +271,9 @@ hipError_t launch_gemm(vt_context* c, const ConvGemmArgs& a, hipStream_t s) {
 }
 
 
-hipError_t launch_halo(vt_context* c, const Conv3x3Args& a, hipStream_t s) {
+hipError_t launch_halo(vt_context* c, const Conv3x3Args& a_in, hipStream_t s) {
+    Conv3x3Args a = a_in;
+    a.occ2 = c->halo_occ2;
     if (!c->profiling) return vt_launch_conv3x3_halo(a, s);
     vt_context::ProfRec r;
     r.e0 = c->next_event(); r.e1 = c->next_event();
@@ -281,7 +303,7 @@ int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int
     int parts = g.parts;
     if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, xdt, B, HW, n.c, groups, g.partial, &parts, s), "gn_stats");
     g.parts = 0;
-    HIPCK(c, vt_launch_gn_finalize(g.partial, parts, B, n.c, groups, 1e-6f, n.g, n.b, g.ss, s), "gn_finalize");
+    HIPCK(c, vt_launch_gn_finalize(g.partial, parts, B, n.c, groups, 1e-6f, n.g, n.b, g.ss, s, c->status), "gn_finalize");
     if (c->profiling) {
         vt_context::ProfRec r;
         r.e0 = c->next_event(); r.e1 = c->next_event();
@@ -320,7 +342,7 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
         h.Wp = w.wp; h.bias = w.b; h.res = res32; h.res_f16 = res16; h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
         if (sc) { h.scX = sc->x; h.scW = sc->wp; h.scCin = sc->cin; h.bias = sc->bias; }
-        if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout, ss != nullptr); }
+        if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout, ss ? (xnorm_f32 ? 1 : 2) : 0, c->halo_occ2, sc != nullptr); }
         HIPCK(c, launch_halo(c, h, s), "conv3x3_halo");
         return VT_OK;
     }
@@ -333,6 +355,7 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     a.x_bs = (long long)Hin * Win * w.cin; a.w_bs = 0; a.o_bs = (long long)Hout * Wout * w.cout; a.r_bs = a.o_bs;
     a.batch = B; a.alpha = 1.f; a.bias_mode = 1; a.out_mode = 0;
     if (fuse && w.cout > 32 && (w.cout % (w.cout <= 128 ? 128 : 256)) == 0) {
+        a.short_tiles = c->gemm_short;
         a.gn_partial = gn->partial; a.gn_cpg = cpg; gn->parts = vt_conv_gemm_ptiles_of(a);
     }
     HIPCK(c, launch_gemm(c, a, s), "conv_gemm");
@@ -359,7 +382,7 @@ int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, 
     int parts = gn.parts;
     if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, xdt, B, H * W, n.c, groups, gn.partial, &parts, s), "gn_stats");
     gn.parts = 0;
-    HIPCK(c, vt_launch_gn_finalize(gn.partial, parts, B, n.c, groups, 1e-6f, n.g, n.b, gn.ss, s), "gn_finalize");
+    HIPCK(c, vt_launch_gn_finalize(gn.partial, parts, B, n.c, groups, 1e-6f, n.g, n.b, gn.ss, s, c->status), "gn_finalize");
     return run_conv(c, w, xdt == 0 ? (const bf16_t*)x : nullptr, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr,
                     groups, xdt == 1 ? (const float*)x : nullptr, gn.ss, rdt);
 }
@@ -481,6 +504,7 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
                 HIPCK(c, vt_launch_attn_qk(k, s), "attn exp scores");
             }
         } else {
+            a.short_tiles = c->gemm_short;
             const int slots = vt_conv_gemm_col_slots(a);
             if ((size_t)slots > attn_slots_bound(S)) return c->fail(VT_ERR_WORKSPACE, "attention: %d column slots exceed the scratch", slots);
             const int* gate = mode == 0 ? sc.flags + b0 / sc.group : nullptr;
@@ -513,6 +537,7 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
         gn->parts = 0;
         const int cpg = C / groups;
         if (c->fuse_gn_stats && (cpg == 4 || cpg == 8 || cpg == 16) && C > 32 && (C % (C <= 128 ? 128 : 256)) == 0) {
+            a.short_tiles = c->gemm_short;
             a.gn_partial = gn->partial; a.gn_cpg = cpg; gn->parts = vt_conv_gemm_ptiles_of(a);
         }
     }
@@ -537,7 +562,7 @@ EncPlan plan_encoder(const EncoderW& e, int B, int H, int W) {
         if (n > p.max_elems) p.max_elems = n;
         if (ch > p.max_c) p.max_c = ch;
         int ck = vt_gn_max_chunks(hh * ww, ch);
-        const int t1 = vt_conv_gemm_ptiles(hh * ww, ch), t2 = vt_conv3x3_halo_tiles(hh, ww, ch, 0), t3 = vt_conv_in_parts(hh, ww);
+        const int t1 = vt_conv_gemm_ptiles(hh * ww, ch), t2 = vt_conv3x3_halo_tiles_max(hh, ww), t3 = vt_conv_in_parts(hh, ww);
         if (t3 > ck) ck = t3;
         const int t4 = vt_conv_in_mfma_parts(hh, ww);
         if (t4 > ck) ck = t4;
@@ -571,23 +596,28 @@ int vt_create(int device, vt_context** out) {
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return VT_ERR_HIP;
-    if (hipSetDevice(device) != hipSuccess) return VT_ERR_HIP;
     vt_context* c = new vt_context();
     c->device = device;
-    if (hipMalloc(&c->zeros, 4096) != hipSuccess || hipMemset(c->zeros, 0, 4096) != hipSuccess) { delete c; return VT_ERR_HIP; }
+    DeviceGuard guard(c);
+    // one zeroed page: DMA source of padded / out-of-image lanes; its last word is the sticky status word
+    if (hipMalloc(&c->zeros, 4096 + 256) != hipSuccess || hipMemset(c->zeros, 0, 4096 + 256) != hipSuccess) { delete c; return VT_ERR_HIP; }
+    c->status = (int*)((char*)c->zeros + 4096);
     *out = c;
     return VT_OK;
 }
 
 void vt_destroy(vt_context* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    if (c->op_scratch) (void)hipFree(c->op_scratch);
-    if (c->rs_host) (void)hipHostFree(c->rs_host);
-    if (c->rs_event) (void)hipEventDestroy(c->rs_event);
-    for (void* p : c->allocs) (void)hipFree(p);
-    if (c->zeros) (void)hipFree(c->zeros);
+    {
+        DeviceGuard guard(c);
+        for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+        if (c->op_scratch) (void)hipFree(c->op_scratch);
+        if (c->rs_host) (void)hipHostFree(c->rs_host);
+        if (c->rs_event) (void)hipEventDestroy(c->rs_event);
+        c->free_allocs(c->enc_allocs);
+        c->free_allocs(c->dec_allocs);
+        if (c->zeros) (void)hipFree(c->zeros);
+    }
     delete c;
 }
 
@@ -600,6 +630,7 @@ int vt_encoder_configure(vt_context* c, int in_ch, int latent, const int* block_
     if (!block_out || n_blocks < 1 || n_blocks > 8 || layers < 1 || layers > 8 || latent < 1 || groups < 1)
         return c->fail(VT_ERR_INVALID, "bad encoder configuration");
     EncoderW& e = c->enc;
+    { DeviceGuard guard(c); c->free_allocs(c->enc_allocs); }       // a re-upload (load_state_dict / .to()) replaces the packed weights
     e = EncoderW();
     e.in_ch = in_ch; e.latent = latent; e.layers = layers; e.groups = groups;
     e.block_out.assign(block_out, block_out + n_blocks);
@@ -633,7 +664,9 @@ int vt_encoder_finalize(vt_context* c) {
     if (!c) return VT_ERR_INVALID;
     EncoderW& e = c->enc;
     if (!e.configured) return c->fail(VT_ERR_STATE, "vt_encoder_configure was not called");
-    HIPCK(c, hipSetDevice(c->device), "hipSetDevice");
+    DeviceGuard guard(c);
+    c->free_allocs(c->enc_allocs);
+    c->cur_allocs = &c->enc_allocs;
     int r;
     const int c0 = e.block_out[0];
     {   // conv_in: [c0][3][3][3] -> [k = ci*9+ky*3+kx][c0] fp32
@@ -726,6 +759,7 @@ double vt_encoder_flops(const vt_context* c, int H, int W) {
 int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, float* latent, void* ws, size_t ws_bytes,
               void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     EncoderW& e = c->enc;
     if (!e.finalized) return c->fail(VT_ERR_STATE, "encoder weights not finalized");
     if (!x || !latent || !ws || B <= 0) return c->fail(VT_ERR_INVALID, "vt_encode: null buffer or B <= 0");
@@ -860,6 +894,7 @@ int vt_decoder_configure(vt_context* c, int num_classes, int latent_channels, in
     if (num_classes < 1 || latent_channels != 16 || heads < 1) return c->fail(VT_ERR_INVALID, "bad decoder configuration (latent_channels must be 16)");
     if (!plain && use_self && (8 % heads)) return c->fail(VT_ERR_INVALID, "attention_heads must divide 8");
     if (!plain && use_cross && (256 % heads)) return c->fail(VT_ERR_INVALID, "attention_heads must divide 256");
+    { DeviceGuard guard(c); c->free_allocs(c->dec_allocs); }
     c->dec = DecoderWeights();
     c->dec.num_classes = num_classes; c->dec.latent_channels = latent_channels; c->dec.plain = plain;
     c->dec.use_spatial = use_spatial; c->dec.use_self = use_self; c->dec.use_cross = use_cross; c->dec.heads = heads;
@@ -879,7 +914,9 @@ static int dec_get(vt_context* c, const char* name, int64_t numel, const float**
 int vt_decoder_finalize(vt_context* c) {
     if (!c) return VT_ERR_INVALID;
     if (!c->dec_configured) return c->fail(VT_ERR_STATE, "vt_decoder_configure was not called");
-    HIPCK(c, hipSetDevice(c->device), "hipSetDevice");
+    DeviceGuard guard(c);
+    c->free_allocs(c->dec_allocs);
+    c->cur_allocs = &c->dec_allocs;
     DecoderWeights& d = c->dec;
     const int C = d.latent_channels, N = d.num_classes;
     int r;
@@ -962,6 +999,7 @@ size_t vt_decode_workspace_bytes(const vt_context* c, int B, int h, int w) {
 int vt_decode_logits(vt_context* c, const float* latent, int B, int h, int w, float* logits, void* ws, size_t ws_bytes,
                      void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     if (!c->dec_finalized) return c->fail(VT_ERR_STATE, "decoder weights not finalized");
     if (!latent || !logits || !ws || B <= 0 || h <= 0 || w <= 0) return c->fail(VT_ERR_INVALID, "vt_decode_logits: bad argument");
     if (ws_bytes < vt_decode_workspace_bytes(c, B, h, w)) return c->fail(VT_ERR_WORKSPACE, "vt_decode_logits: workspace too small");
@@ -971,9 +1009,31 @@ int vt_decode_logits(vt_context* c, const float* latent, int B, int h, int w, fl
 
 int vt_get_confidence(vt_context* c, const float* logits, int B, int N, float* conf, int64_t* idx, void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     if (!logits || !conf || !idx || B <= 0 || N <= 0) return c->fail(VT_ERR_INVALID, "vt_get_confidence: bad argument");
-    if (N > 16384) return c->fail(VT_ERR_INVALID, "vt_get_confidence: N = %d > 16384 tags is not supported by the LDS sort", N);
     HIPCK(c, vt_decoder_sort(logits, B, N, conf, (long long*)idx, (hipStream_t)stream), "decoder_sort");
+    return VT_OK;
+}
+
+int vt_summarize_confidence(vt_context* c, const float* conf, const int64_t* idx, int B, int N, float threshold, int K,
+                            float* top_conf, int32_t* top_idx, float* stats, void* stream) {
+    if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
+    if (!conf || !idx || !top_conf || !top_idx || !stats || B <= 0 || N <= 0 || K <= 0) return c->fail(VT_ERR_INVALID, "vt_summarize_confidence: bad argument");
+    HIPCK(c, vt_decoder_summary(conf, (const long long*)idx, B, N, threshold, K, top_conf, (int*)top_idx, stats, (hipStream_t)stream), "decoder_summary");
+    return VT_OK;
+}
+
+int vt_status(vt_context* c, int clear, int* status_out, void* stream) {
+    if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
+    if (!status_out) return c->fail(VT_ERR_INVALID, "vt_status: null output");
+    hipStream_t s = (hipStream_t)stream;
+    int v = 0;
+    HIPCK(c, hipMemcpyAsync(&v, c->status, sizeof(int), hipMemcpyDeviceToHost, s), "vt_status copy");
+    if (clear) HIPCK(c, hipMemsetAsync(c->status, 0, sizeof(int), s), "vt_status clear");
+    HIPCK(c, hipStreamSynchronize(s), "vt_status sync");
+    *status_out = v;
     return VT_OK;
 }
 
@@ -1007,10 +1067,10 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 0) { c->use_halo_conv = value != 0; return VT_OK; }
     if (flag == 1) { c->fuse_gn_stats = value != 0; return VT_OK; }
     if (flag == 2) { c->fuse_gn_apply = value != 0; return VT_OK; }
-    if (flag == 3) { vt_conv3x3_halo_set_occ2(value); return VT_OK; }       // process-wide: halo kernel geometry
+    if (flag == 3) { c->halo_occ2 = value < 0 ? 0 : (value > 3 ? 3 : value); return VT_OK; }
     if (flag == 4) { c->res_fp16 = value != 0; return VT_OK; }
     if (flag == 5) { c->conv_in_mfma = value != 0; return VT_OK; }
-    if (flag == 6) { vt_conv_gemm_set_short(value); return VT_OK; }         // process-wide: GEMM tile choice
+    if (flag == 6) { c->gemm_short = value != 0; return VT_OK; }
     if (flag == 8) { c->fuse_shortcut = value != 0; return VT_OK; }
     if (flag == 9) { c->attn_qk_kernel = value != 0; return VT_OK; }
     if (flag == 10) { c->pv_stream = value != 0; return VT_OK; }
@@ -1026,6 +1086,7 @@ int vt_profile_num_configs(void) { return VT_NUM_PROF_SLOTS; }
 
 int vt_preprocess_u8(vt_context* c, const uint8_t* in_hwc, int B, int H, int W, float* out_nchw, void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     HIPCK(c, vt_launch_preprocess_u8(in_hwc, out_nchw, B, H, W, (hipStream_t)stream), "vt_preprocess_u8");
     return VT_OK;
 }
@@ -1108,7 +1169,7 @@ int vt_resize_u8(vt_context* c, const uint8_t* src_hwc, int src_h, int src_w, in
     if (!src_hwc || !dst_hwc || (filter != 0 && filter != 1) || crop_w <= 0 || crop_h <= 0 || dst_w <= 0 || dst_h <= 0 ||
         crop_left < 0 || crop_top < 0 || crop_left + crop_w > src_w || crop_top + crop_h > src_h)
         return c->fail(VT_ERR_INVALID, "vt_resize_u8: bad argument");
-    HIPCK(c, hipSetDevice(c->device), "hipSetDevice");
+    DeviceGuard guard(c);
     const RsPlan p = rs_plan(crop_h, crop_w, dst_h, dst_w, filter);
     char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (p.total && (!workspace || workspace_bytes < p.total + (size_t)(ws - (char*)workspace)))
@@ -1146,6 +1207,7 @@ int vt_profile_begin(vt_context* c) {
 int vt_profile_end(vt_context* c, int max_cfg, long long* launches, double* total_ms, double* total_flops,
                    const char** names) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     c->profiling = false;
     if (max_cfg < VT_NUM_PROF_SLOTS || !launches || !total_ms || !total_flops) return c->fail(VT_ERR_INVALID, "vt_profile_end: need room for %d slots", VT_NUM_PROF_SLOTS);
     for (int i = 0; i < VT_NUM_PROF_SLOTS; ++i) { launches[i] = 0; total_ms[i] = 0; total_flops[i] = 0; if (names) names[i] = vt_conv_gemm_config_name(i); }
@@ -1163,6 +1225,7 @@ int vt_profile_end(vt_context* c, int max_cfg, long long* launches, double* tota
 int vt_op_conv2d(vt_context* c, const void* x, const void* w, const float* bias, const float* res, float* o32, void* o16,
                  int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int pad_lo, int pad_hi, void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     if (!x || !w || (!o32 && !o16)) return c->fail(VT_ERR_INVALID, "vt_op_conv2d: null buffer");
     if (stride < 1 || pad_lo < 0 || pad_hi < 0) return c->fail(VT_ERR_INVALID, "vt_op_conv2d: bad stride/pad");
     const int Hout = (Hin + pad_lo + pad_hi - ksize) / stride + 1, Wout = (Win + pad_lo + pad_hi - ksize) / stride + 1;
@@ -1197,6 +1260,7 @@ int vt_op_norm_silu_conv3x3(vt_context* c, const void* x, int x_dtype, const flo
                             const float* bias, const float* res, float* o32, void* o16, int B, int H, int W, int Cin,
                             int Cout, void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     if (!x || !scale_shift || !w || (!o32 && !o16)) return c->fail(VT_ERR_INVALID, "vt_op_norm_silu_conv3x3: null buffer");
     if (x_dtype != VT_F32 && x_dtype != VT_BF16) return c->fail(VT_ERR_INVALID, "vt_op_norm_silu_conv3x3: x must be f32 or bf16");
     if (!vt_conv3x3_halo_supported(Cin, Cout) || Cin * 8 > 8192) return c->fail(VT_ERR_INVALID, "vt_op_norm_silu_conv3x3: unsupported channel counts %d -> %d", Cin, Cout);
@@ -1220,7 +1284,7 @@ int vt_op_norm_silu_conv3x3(vt_context* c, const void* x, int x_dtype, const flo
 size_t vt_op_conv2d_gn_workspace_bytes(int B, int Hout, int Wout, int Cout) {
     if (B <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0) return 0;
     int parts = vt_conv_gemm_ptiles(Hout * Wout, Cout);
-    const int t2 = vt_conv3x3_halo_tiles(Hout, Wout, Cout, 0);
+    const int t2 = vt_conv3x3_halo_tiles_max(Hout, Wout);
     if (t2 > parts) parts = t2;
     return align_up((size_t)B * parts * 64 * 3 * 4);
 }
@@ -1230,6 +1294,7 @@ int vt_op_conv2d_gn(vt_context* c, const void* x, const void* w, const float* bi
                     int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int pad_lo, int pad_hi, int groups,
                     float eps, const float* gamma, const float* beta, float* scale_shift, void* ws, void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     if (!gamma || !beta || !scale_shift || !ws || groups < 1 || groups > 64 || Cout % groups) return c->fail(VT_ERR_INVALID, "vt_op_conv2d_gn: bad argument");
     const int cpg = Cout / groups;
     if (cpg != 4 && cpg != 8 && cpg != 16) return c->fail(VT_ERR_INVALID, "vt_op_conv2d_gn: channels per group must be 4, 8 or 16");
@@ -1262,6 +1327,7 @@ int vt_op_gemm_nt(vt_context* c, const void* A, const void* Bm, const float* bia
                   int N, int K, int lda, int ldb, int ldo, long long a_bs, long long b_bs, long long o_bs, float alpha,
                   int bias_per_row, void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     if (!A || !Bm || (!o32 && !o16)) return c->fail(VT_ERR_INVALID, "vt_op_gemm_nt: null buffer");
     ConvGemmArgs a{};
     a.X = (const bf16_t*)A; a.W = (const bf16_t*)Bm; a.bias = bias; a.out_f32 = o32; a.out_bf16 = (bf16_t*)o16; a.zeros = c->zeros;
@@ -1275,6 +1341,7 @@ int vt_op_gemm_nt(vt_context* c, const void* A, const void* Bm, const float* bia
 int vt_op_conv_in(vt_context* c, const float* x, const float* w_oihw, const float* bias, float* o32, void* o16, int B,
                   int H, int W, int Cout, void* ws, void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     if (!x || !w_oihw || !bias || !ws) return c->fail(VT_ERR_INVALID, "vt_op_conv_in: null buffer");
     // device-side repack is not worth a kernel for a test entry point: weights arrive on the DEVICE in OIHW,
     // are copied to the host, packed [27][Cout] and written into `ws` (>= 27*Cout*4 bytes).  Synchronises.
@@ -1302,6 +1369,7 @@ size_t vt_op_groupnorm_workspace_bytes(int B, int HW, int C) {
 int vt_op_groupnorm(vt_context* c, const void* x, int x_dtype, int B, int HW, int C, int groups, float eps,
                     const float* gamma, const float* beta, int silu, void* y, void* ws, void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     if (!x || !gamma || !beta || !y || !ws) return c->fail(VT_ERR_INVALID, "vt_op_groupnorm: null buffer");
     if (x_dtype != VT_F32 && x_dtype != VT_BF16 && x_dtype != VT_F16) return c->fail(VT_ERR_INVALID, "vt_op_groupnorm: dtype must be f32, bf16 or f16");
     if (groups > 64) return c->fail(VT_ERR_INVALID, "vt_op_groupnorm: groups > 64");
@@ -1318,6 +1386,7 @@ int vt_op_groupnorm(vt_context* c, const void* x, int x_dtype, int B, int HW, in
 
 int vt_op_softmax_rows(vt_context* c, const float* scores, void* probs, int rows, int n, int lds, int ldp, void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     HIPCK(c, vt_launch_softmax_rows(scores, 0, (bf16_t*)probs, rows, n, lds, ldp, (hipStream_t)stream), "vt_op_softmax_rows");
     return VT_OK;
 }
@@ -1329,6 +1398,7 @@ size_t vt_op_attention_workspace_bytes(int B, int S, int C) {
 
 int vt_op_attention(vt_context* c, const void* x16, const float* res, float* out, int B, int S, int C, void* ws, void* stream) {
     if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
     if (!c->enc.finalized) return c->fail(VT_ERR_STATE, "encoder weights not finalized");
     if (C != c->enc.attn.c) return c->fail(VT_ERR_INVALID, "vt_op_attention: C = %d but the mid-block attention has %d channels", C, c->enc.attn.c);
     if (!x16 || !out || !ws || ((uintptr_t)ws % ALIGN)) return c->fail(VT_ERR_INVALID, "vt_op_attention: bad buffer");

@@ -632,13 +632,10 @@ hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
     constexpr int NXW = ((HROWS + 15) / 16 + NWV - 1) / NWV;
     const int smem = 2 * NXW * NWV * 16 * HB + NW * BC * HB + (XT ? a.Cin * 8 : 0);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_done{0};
     auto kern = conv3x3_halo_kernel<WP, WC, XT, TPW, NW>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t ea = vt_once_per_device(attr_done, [&] { return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    if (ea != hipSuccess) return ea;
     const long long tiles = (long long)((a.W + TW - 1) / TW) * ((a.H + ROWS - 1) / ROWS);
     const long long nblk = tiles * (a.Cout / BC) * a.batch;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -666,28 +663,49 @@ hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w, bf16_t* wp, int Cin, i
     return hipGetLastError();
 }
 
-// Two-workgroups-per-CU tiles for plain-input layers (vt_set_flag(ctx, 3, mode)): while one workgroup runs its prologue /
-// epilogue (~12 us of VALU, latency and stores per tile) the other one has the matrix pipes.
+// Two-workgroups-per-CU tiles for plain-input layers (Conv3x3Args::occ2 = vt_set_flag(ctx, 3, mode)): while one workgroup runs
+// its prologue / epilogue (~12 us of VALU, latency and stores per tile) the other one has the matrix pipes.
 //   0 off; 1 = 128-cout layers on 8 waves x 128 VGPRs (16x16 px x 128 couts, wave tile 64 px x 64 couts);
 //   2 = 128-cout layers on 4 waves x 256 VGPRs (same tile, wave tile 128 px x 64 couts, halo rows reused across ky);
 //   3 = mode 2 for EVERY plain-input layer (256-cout layers run two 128-cout tiles per pixel tile).
-int g_halo_occ2 = 3;
+// ONE function decides the kernel variant; the launcher, the profile slot and the GroupNorm-partials count all use it.
+namespace {
+enum HaloVariant { HV_2208_4 = 0, HV_4204_4, HV_4208_6, HV_2408_6, HV_XT1_128, HV_XT1_256, HV_XT2_128, HV_XT2_256 };
+HaloVariant halo_variant(int Cout, int xt, int occ2, bool has_sc) {
+    const bool big = (Cout % 256) == 0;                     // 16x16 px x 256 couts, else 32x16 px x 128 couts
+    if (xt == 1) return big ? HV_XT1_256 : HV_XT1_128;
+    if (xt == 2) return big ? HV_XT2_256 : HV_XT2_128;
+    if (occ2 == 3 || (occ2 == 2 && !big)) return HV_2208_4;                     // 4 waves, 2 workgroups / CU
+    if (occ2 && !big && !has_sc) return HV_4204_4;          // (the 128-VGPR tile has no registers for the fused shortcut)
+    return big ? HV_2408_6 : HV_4208_6;
+}
+int halo_variant_rows(HaloVariant v) {
+    switch (v) {
+        case HV_4208_6: case HV_XT1_128: case HV_XT2_128: return 32;
+        default: return 16;
+    }
+}
+}  // namespace
 
-int vt_conv3x3_halo_tiles(int H, int W, int Cout, int fused_norm) {
-    // must match the tile the dispatcher below picks: 256-cout tiles have 16 rows; 128-cout tiles 16 rows in the
-    // two-workgroups-per-CU variant (plain bf16 input only) and 32 rows otherwise
-    const int rows = (Cout % 256) == 0 ? 16 : ((g_halo_occ2 && !fused_norm) ? 16 : 32);
+int vt_conv3x3_halo_tiles(int H, int W, int Cout, int xt, int occ2, int has_sc) {
+    const int rows = halo_variant_rows(halo_variant(Cout, xt, occ2, has_sc != 0));
     return ((W + TW - 1) / TW) * ((H + rows - 1) / rows);
 }
-
-void vt_conv3x3_halo_set_occ2(int mode) { g_halo_occ2 = mode < 0 ? 0 : (mode > 3 ? 3 : mode); }
-int vt_conv3x3_halo_occ2(void) { return g_halo_occ2; }
+int vt_conv3x3_halo_tiles_max(int H, int W) { return ((W + TW - 1) / TW) * ((H + 15) / 16); }
 
 bool vt_conv3x3_halo_supported(int Cin, int Cout) { return Cin >= 32 && (Cin % 32) == 0 && (Cout % 128) == 0; }
 
-int vt_conv3x3_halo_config(const Conv3x3Args& a) {      // profile slots 3..8 = <tile, XT>
-    const int xt = a.scale_shift ? (a.Xf32 ? 1 : 2) : 0;
-    return 3 + 2 * xt + ((a.Cout % 256) == 0 ? 1 : 0);
+static int halo_xt(const Conv3x3Args& a) { return a.scale_shift ? (a.Xf32 ? 1 : 2) : 0; }
+
+int vt_conv3x3_halo_config(const Conv3x3Args& a) {      // profile slots 3..8
+    switch (halo_variant(a.Cout, halo_xt(a), a.occ2, a.scX != nullptr)) {
+        case HV_2208_4: return 3;
+        case HV_4204_4: return 4;
+        case HV_4208_6: return 5;
+        case HV_2408_6: return 6;
+        case HV_XT1_128: case HV_XT1_256: return 7;
+        default: return 8;
+    }
 }
 
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
@@ -699,15 +717,18 @@ hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
     if ((a.scX != nullptr) != (a.scW != nullptr)) return hipErrorInvalidValue;
     if (a.scX && (a.scCin <= 0 || (a.scCin % 32) || a.scale_shift || (long long)a.H * a.W * a.scCin >= (1LL << 31))) return hipErrorInvalidValue;
     if ((long long)(a.Cin / 32) * 9 * a.Cout * 32 >= (1LL << 31)) return hipErrorInvalidValue;
+    if (a.occ2 < 0 || a.occ2 > 3) return hipErrorInvalidValue;
     // input mode: raw bf16 (X), or GroupNorm+SiLU fused into the staging of an fp32 (Xf32) / bf16 (X) tensor
-    const int xt = a.scale_shift ? (a.Xf32 ? 1 : 2) : 0;
+    const int xt = halo_xt(a);
     if (xt == 1 ? (a.X != nullptr) : (a.X == nullptr || a.Xf32 != nullptr)) return hipErrorInvalidValue;
-    const bool big = (a.Cout % 256) == 0;                   // 16x16 px x 256 couts, else 32x16 px x 128 couts
-    if (xt == 0) {
-        if (g_halo_occ2 == 3 || (g_halo_occ2 == 2 && !big)) return launch<2, 2, 0, 8, 4>(a, s);   // 4 waves, 2 workgroups / CU
-        if (g_halo_occ2 && !big && !a.scX) return launch<4, 2, 0, 4, 4>(a, s);           // 16x16 px x 128 couts, 2 workgroups / CU
-        return big ? launch<2, 4, 0, 8>(a, s) : launch<4, 2, 0, 8>(a, s);
+    switch (halo_variant(a.Cout, xt, a.occ2, a.scX != nullptr)) {
+        case HV_2208_4: return launch<2, 2, 0, 8, 4>(a, s);
+        case HV_4204_4: return launch<4, 2, 0, 4, 4>(a, s);
+        case HV_4208_6: return launch<4, 2, 0, 8>(a, s);
+        case HV_2408_6: return launch<2, 4, 0, 8>(a, s);
+        case HV_XT1_128: return launch<4, 2, 1, 8>(a, s);
+        case HV_XT1_256: return launch<2, 4, 1, 8>(a, s);
+        case HV_XT2_128: return launch<4, 2, 2, 8>(a, s);
+        default: return launch<2, 4, 2, 8>(a, s);
     }
-    if (xt == 1) return big ? launch<2, 4, 1, 8>(a, s) : launch<4, 2, 1, 8>(a, s);
-    return big ? launch<2, 4, 2, 8>(a, s) : launch<4, 2, 2, 8>(a, s);
 }

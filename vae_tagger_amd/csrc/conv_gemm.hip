@@ -362,15 +362,15 @@ template <int BP, int BC, int WP, int WC, bool OCC2 = false>
 hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BP + BC) * ROWB;
     static_assert(!OCC2 || smem <= 80 * 1024, "two workgroups per CU");
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_done{0};
     auto kern = conv_gemm_kernel<BP, BC, WP, WC, OCC2>;
     auto gated = conv_gemm_gated_kernel<BP, BC, WP, WC, OCC2>;
-    if (!attr_set) {
+    hipError_t ea = vt_once_per_device(attr_done, [&] {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gated, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+        return e;
+    });
+    if (ea != hipSuccess) return ea;
     const int HWo = a.Hout * a.Wout;
     const int ptiles = (HWo + BP - 1) / BP, ctiles = (a.Cout + BC - 1) / BC;
     const long long nblk = (long long)ptiles * ctiles * a.batch;
@@ -432,25 +432,20 @@ int vt_conv_gemm_col_slots(const ConvGemmArgs& a) {
     return (a.Cout + bc - 1) / bc * wc;
 }
 
-int g_gemm_short = 1;      // short-K launches use the two-workgroups-per-CU tile (vt_set_flag 6)
-void vt_conv_gemm_set_short(int on) { g_gemm_short = on != 0; }
-
 int vt_conv_gemm_config(const ConvGemmArgs& a) {
     if (a.Cout <= 32) return 0;
     // the 128-cout stride-2 conv (18 K-steps per tile) gains the same way from a second resident workgroup
-    if (a.Cout == 128 && g_gemm_short && a.ksize == 3 && a.out_mode == 0) return 9;
+    if (a.Cout == 128 && a.short_tiles && a.ksize == 3 && a.out_mode == 0) return 9;
     if (a.Cout <= 128) return 1;
     // 1x1 / GEMM launches with K <= 512 spend most of a 256x256 tile's life in its prologue and epilogue
-    if (g_gemm_short && a.ksize == 1 && a.Cin <= 512 && (a.Cout % 128) == 0 && a.out_mode == 0) return 9;
+    if (a.short_tiles && a.ksize == 1 && a.Cin <= 512 && (a.Cout % 128) == 0 && a.out_mode == 0) return 9;
     return 2;
 }
 const char* vt_conv_gemm_config_name(int cfg) {
     static const char* n[VT_NUM_PROF_SLOTS] = {"conv_gemm_kernel<128,32,8,1>", "conv_gemm_kernel<256,128,4,2>",
-                                               "conv_gemm_kernel<256,256,2,4>", "conv3x3_halo_kernel<4,2,0,4,4>",
-                                               "conv3x3_halo_kernel<2,4,0,8,6>", "conv3x3_halo_kernel<4,2,1,8,6>",
-                                               "conv3x3_halo_kernel<2,4,1,8,6>", "conv3x3_halo_kernel<4,2,2,8,6>",
-                                               "conv3x3_halo_kernel<2,4,2,8,6>", "conv_gemm_kernel<192,128,4,2,occ2>", "attn_qk_kernel", "gn_apply_kernel"};
-    if (cfg == 3 && !vt_conv3x3_halo_occ2()) return "conv3x3_halo_kernel<4,2,0,8,6>";
-    if ((cfg == 3 && vt_conv3x3_halo_occ2() >= 2) || (cfg == 4 && vt_conv3x3_halo_occ2() == 3)) return "conv3x3_halo_kernel<2,2,0,8,4>";
+                                               "conv_gemm_kernel<256,256,2,4>", "conv3x3_halo_kernel<2,2,0,8,4>",
+                                               "conv3x3_halo_kernel<4,2,0,4,4>", "conv3x3_halo_kernel<4,2,0,8,6>",
+                                               "conv3x3_halo_kernel<2,4,0,8,6>", "conv3x3_halo_kernel<.,.,1,8,6>",
+                                               "conv3x3_halo_kernel<.,.,2,8,6>", "conv_gemm_kernel<192,128,4,2,occ2>", "attn_qk_kernel", "gn_apply_kernel"};
     return (cfg >= 0 && cfg < VT_NUM_PROF_SLOTS) ? n[cfg] : "?";
 }

@@ -316,37 +316,121 @@ __global__ void dec_add_kernel(float* __restrict__ a, const float* __restrict__ 
     if (i < n) a[i] += b[i];
 }
 
-// get_confidence: bitonic sort of (logit desc, index asc) in LDS, one workgroup per image.
-__global__ __launch_bounds__(1024) void dec_sort_kernel(const float* __restrict__ logits, int N, int NP,
-                                                        float* __restrict__ conf, long long* __restrict__ idx) {
+// ---- get_confidence: descending sort of (logit, tag index) per image ------------------------------------------------
+// One 64-bit key per tag whose unsigned order IS the output order: high word = the logit mapped to a monotone unsigned
+// (NaN -> 1: after every real value, -inf included), low word = ~index (equal logits: ascending index).  Keys are unique, so
+// the order is strict and total.  The network is the single-direction ("flip") bitonic sort: stage k compares i with
+// i ^ (2k' - 1) first and then i ^ j for j = k'/2 .. 1, every exchange in the same direction, so tags beyond N are virtual
+// minimum keys that never move and N needs no power-of-two padding.  Up to SORT_CH tags the whole sort runs in LDS in one
+// launch; beyond that each 16384-block is sorted in LDS, the j > SORT_CH/2 steps of the later stages run as global-memory
+// passes over the key array (kept in the int64 index output) and each stage's tail runs in LDS again.
+constexpr int SORT_CH = 16384;
+
+__device__ __forceinline__ unsigned long long sort_key(float f, int i) {
+    unsigned u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;                             // -0.0 ties with +0.0, as in a comparison sort
+    u = (f != f) ? 1u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+    return ((unsigned long long)u << 32) | (unsigned)(~i);
+}
+__device__ __forceinline__ float sort_key_logit(unsigned long long k) {
+    const unsigned u = (unsigned)(k >> 32);
+    if (u == 1u) return __uint_as_float(0x7fc00000u);
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// MODE 0: build the keys of block c from the logits and sort the block (stages k = 2 .. SORT_CH).
+// MODE 1: load the keys of block c and run the steps j = SORT_CH/2 .. 1 of a later stage.
+// `final`: write sigmoid(conf) / int64 indices instead of keys.
+template <int MODE>
+__global__ __launch_bounds__(1024) void dec_sort_local_kernel(const float* __restrict__ logits, int N,
+                                                              unsigned long long* __restrict__ keys,
+                                                              float* __restrict__ conf, long long* __restrict__ idx, int final) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    float* key = (float*)sm;
-    int* id = (int*)(sm + (size_t)NP * 4);
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < NP; i += 1024) {
-        key[i] = i < N ? logits[(long long)b * N + i] : -INFINITY;
-        id[i] = i < N ? i : 0x7fffffff;
+    unsigned long long* key = (unsigned long long*)sm;
+    const int b = blockIdx.y, base = blockIdx.x * SORT_CH;
+    const int n = min(SORT_CH, N - base);                    // real elements of this block
+    int np = 2;
+    while (np < n) np <<= 1;
+    for (int i = threadIdx.x; i < np; i += 1024) {
+        unsigned long long k = 0ull;
+        if (i < n) k = MODE == 0 ? sort_key(logits[(long long)b * N + base + i], base + i) : keys[(long long)b * N + base + i];
+        key[i] = k;
     }
     __syncthreads();
-    // "a before b" <=> key larger, or equal key and smaller index.  NaN logits sort last.
-    for (int k = 2; k <= NP; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < NP; i += 1024) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const float ka = key[i], kb = key[l];
-                    const int ia = id[i], ib = id[l];
-                    const bool a_first = (ka > kb) || (ka == kb && ia < ib) || (kb != kb && ka == ka);
-                    const bool up = (i & k) == 0;       // ascending position order in this block
-                    if (up ? !a_first : a_first) { key[i] = kb; key[l] = ka; id[i] = ib; id[l] = ia; }
-                }
+    auto step = [&](int j, bool flip, int kk) {
+        for (int i = threadIdx.x; i < np; i += 1024) {
+            const int l = flip ? (i ^ (kk - 1)) : (i ^ j);
+            if (l > i && l < n) {
+                const unsigned long long a = key[i], c = key[l];
+                if (a < c) { key[i] = c; key[l] = a; }       // descending
             }
-            __syncthreads();
+        }
+        __syncthreads();
+    };
+    if (MODE == 0) {
+        for (int k = 2; k <= np; k <<= 1) {
+            step(0, true, k);
+            for (int j = k >> 2; j > 0; j >>= 1) step(j, false, 0);
+        }
+    } else {
+        for (int j = SORT_CH >> 1; j > 0; j >>= 1) step(j, false, 0);
+    }
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const long long o = (long long)b * N + base + i;
+        if (final) {
+            conf[o] = vt_sigmoid_accurate(sort_key_logit(key[i]));
+            idx[o] = (long long)(int)(~(unsigned)key[i]);
+        } else {
+            keys[o] = key[i];
         }
     }
-    for (int i = threadIdx.x; i < N; i += 1024) {
-        conf[(long long)b * N + i] = vt_sigmoid_accurate(key[i]);
-        idx[(long long)b * N + i] = (long long)id[i];
+}
+
+// one global-memory step of stage k: flip (partner i ^ (k - 1)) or plain (partner i ^ j); pairs with a partner >= N stay
+__global__ __launch_bounds__(256) void dec_sort_global_kernel(unsigned long long* __restrict__ keys, int N, int k, int j, int flip) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;            // pair number
+    const int half = flip ? (k >> 1) : j;
+    const int i = ((t / half) * 2) * half + (t % half);      // lower element of pair t
+    const int l = flip ? (i ^ (k - 1)) : (i ^ j);
+    if (l >= N || i >= N) return;
+    unsigned long long* kb = keys + (long long)b * N;
+    const unsigned long long a = kb[i], c = kb[l];
+    if (a < c) { kb[i] = c; kb[l] = a; }
+}
+
+// ---- per-image summary of the sorted confidences (infer_full.py:106-125) on the device: the number of tags at or above the
+// threshold, the first K (confidence, index) pairs, the maximum and the top-5 mean (the sum of the first five divided by 5,
+// whatever N is) -- B x (2 K + 4) values cross PCIe instead of B x N x 12 bytes.
+// stats[b] = { count >= threshold, max confidence, top-5 sum / 5, number of non-finite confidences }
+__global__ __launch_bounds__(256) void dec_summary_kernel(const float* __restrict__ conf, const long long* __restrict__ idx, int N,
+                                                          float threshold, int K, float* __restrict__ top_conf,
+                                                          int* __restrict__ top_idx, float* __restrict__ stats) {
+    __shared__ int s_cnt, s_bad;
+    const int b = blockIdx.x;
+    const float* c = conf + (long long)b * N;
+    const long long* ix = idx + (long long)b * N;
+    if (threadIdx.x == 0) { s_cnt = 0; s_bad = 0; }
+    __syncthreads();
+    int cnt = 0, bad = 0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float v = c[i];
+        cnt += v >= threshold;                               // the reference's test, element by element (NaN fails it)
+        bad += !(fabsf(v) <= 3.0e38f);
+    }
+    atomicAdd(&s_cnt, cnt);
+    atomicAdd(&s_bad, bad);
+    for (int i = threadIdx.x; i < K; i += 256) {
+        top_conf[(long long)b * K + i] = i < N ? c[i] : 0.f;
+        top_idx[(long long)b * K + i] = i < N ? (int)ix[i] : -1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s5 = 0.f;
+        for (int i = 0; i < 5 && i < N; ++i) s5 += c[i];
+        float mx = c[0];
+        float* o = stats + (long long)b * 4;
+        o[0] = (float)s_cnt; o[1] = mx; o[2] = s5 / 5.0f; o[3] = (float)s_bad;
     }
 }
 
@@ -428,13 +512,36 @@ size_t vt_decoder_workspace_floats(int B, int C, int H, int Wd) {
 }
 
 hipError_t vt_decoder_sort(const float* logits, int B, int N, float* conf, long long* idx, hipStream_t s) {
-    int NP = 1;
-    while (NP < N) NP <<= 1;
-    if (NP < 2) NP = 2;
-    if (N <= 0 || NP > 16384) return hipErrorInvalidValue;
-    const size_t smem = (size_t)NP * 8;
-    static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute((const void*)dec_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8)); attr = true; }
-    hipLaunchKernelGGL(dec_sort_kernel, dim3(B), dim3(1024), smem, s, logits, N, NP, conf, idx); CKL();
+    if (N <= 0 || B <= 0) return hipErrorInvalidValue;
+    static std::atomic<unsigned long long> attr_done{0};
+    CK(vt_once_per_device(attr_done, [&] {
+        hipError_t e = hipFuncSetAttribute((const void*)dec_sort_local_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_CH * 8);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_sort_local_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_CH * 8);
+        return e;
+    }));
+    const int chunks = (N + SORT_CH - 1) / SORT_CH;
+    unsigned long long* keys = (unsigned long long*)idx;      // the int64 index output doubles as the key array
+    int np = 2;
+    while (np < (N < SORT_CH ? N : SORT_CH)) np <<= 1;
+    const size_t smem = (size_t)np * 8;
+    hipLaunchKernelGGL(dec_sort_local_kernel<0>, dim3(chunks, B), dim3(1024), smem, s, logits, N, keys, conf, idx, chunks == 1 ? 1 : 0); CKL();
+    if (chunks == 1) return hipSuccess;
+    long long top = SORT_CH;
+    while (top < N) top <<= 1;
+    const unsigned pair_blocks = (unsigned)((top / 2 + 255) / 256);
+    for (long long k = 2LL * SORT_CH; k <= top; k <<= 1) {
+        hipLaunchKernelGGL(dec_sort_global_kernel, dim3(pair_blocks, B), dim3(256), 0, s, keys, N, (int)k, 0, 1); CKL();
+        for (long long j = k >> 2; j >= SORT_CH; j >>= 1) {
+            hipLaunchKernelGGL(dec_sort_global_kernel, dim3(pair_blocks, B), dim3(256), 0, s, keys, N, (int)k, (int)j, 0); CKL();
+        }
+        hipLaunchKernelGGL(dec_sort_local_kernel<1>, dim3(chunks, B), dim3(1024), (size_t)SORT_CH * 8, s, logits, N, keys, conf, idx, k == top ? 1 : 0); CKL();
+    }
+    return hipSuccess;
+}
+
+hipError_t vt_decoder_summary(const float* conf, const long long* idx, int B, int N, float threshold, int K, float* top_conf,
+                              int* top_idx, float* stats, hipStream_t s) {
+    if (B <= 0 || N <= 0 || K <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dec_summary_kernel, dim3(B), dim3(256), 0, s, conf, idx, N, threshold, K, top_conf, top_idx, stats); CKL();
     return hipSuccess;
 }

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nparts, int C,
                                                          int groups, float eps, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
-                                                         float* __restrict__ scale_shift) {
+                                                         float* __restrict__ scale_shift, int* __restrict__ status) {
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int cpg = C / groups;
     const float* pb = partial + ((long long)b * nparts * groups + g) * 3;
@@ -153,6 +153,9 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
     const double var = m2 / n;
+    // every tensor of the path passes through here: inf / NaN statistics (an fp16-stored activation beyond +-65504, or a
+    // checkpoint with NaN weights) raise the sticky status bit the host reads with vt_status -- the outputs are garbage then
+    if (status && lane == 0 && !(fabs(mean) <= 1.0e300 && fabs(var) <= 1.0e300)) atomicOr(status, 1);
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float fmean = (float)mean;
     for (int c = lane; c < cpg; c += 64) {
@@ -242,10 +245,10 @@ hipError_t vt_launch_gn_stats(const void* x, int x_dtype, int B, int HW, int C, 
 }
 
 hipError_t vt_launch_gn_finalize(const float* partial, int nparts, int B, int C, int groups, float eps,
-                                 const float* gamma, const float* beta, float* scale_shift, hipStream_t s) {
+                                 const float* gamma, const float* beta, float* scale_shift, hipStream_t s, int* status) {
     if (C <= 0 || groups <= 0 || C % groups || nparts <= 0 || B <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, s, partial, nparts, C, groups, eps, gamma,
-                       beta, scale_shift);
+                       beta, scale_shift, status);
     return hipGetLastError();
 }
 

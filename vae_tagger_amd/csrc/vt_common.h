@@ -11,6 +11,22 @@ typedef _Float16 f16_t;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: launchers call it once per device
+// (bit = current device id; racing first calls at worst set the attribute twice).  `set` performs the hipFuncSetAttribute calls.
+#include <atomic>
+template <typename F>
+inline hipError_t vt_once_per_device(std::atomic<unsigned long long>& done, F set) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = set();
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+
 #define VT_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define VT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 

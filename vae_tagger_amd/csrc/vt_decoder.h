@@ -30,3 +30,5 @@ hipError_t vt_decoder_forward(const DecoderWeights& w, const float* latent_nchw,
                               float* logits, hipStream_t s);
 size_t vt_decoder_workspace_floats(int B, int C, int H, int W);
 hipError_t vt_decoder_sort(const float* logits, int B, int N, float* conf, long long* idx, hipStream_t s);
+hipError_t vt_decoder_summary(const float* conf, const long long* idx, int B, int N, float threshold, int K, float* top_conf,
+                              int* top_idx, float* stats, hipStream_t s);

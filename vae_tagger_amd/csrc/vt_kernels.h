@@ -38,6 +38,7 @@ struct ConvGemmArgs {
     const int* gate;        // optional: the whole launch is a no-op unless *gate == gate_expect
     int gate_expect;
     int x_stream;           // 1 = X is read once (P of P.V): its LDS-DMA carries the streaming (nt) cache policy
+    int short_tiles;        // 1 = short-K launches and the 128-cout stride-2 conv use the two-workgroups-per-CU tile (vt_set_flag 6)
 };
 int vt_conv_gemm_col_slots(const ConvGemmArgs& a);
 
@@ -49,7 +50,6 @@ constexpr int VT_NUM_MFMA_CONFIGS = 11;  // 0..2 conv_gemm tiles, 3..8 conv3x3_h
 constexpr int VT_PROF_ATTN_QK = 10;
 constexpr int VT_PROF_GN_APPLY = 11;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
 constexpr int VT_NUM_PROF_SLOTS = 12;
-void vt_conv_gemm_set_short(int on);     // short-K launches: two-workgroups-per-CU tile (default on)
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
@@ -89,13 +89,14 @@ struct Conv3x3Args {
     const bf16_t* scX;      // NHWC bf16 [batch][H][W][scCin]
     const bf16_t* scW;      // packed [scCin/32][Cout][32] bf16, rows in the interleaved cout order
     int scCin;
+    int occ2;               // two-workgroups-per-CU tile mode 0..3 (vt_set_flag 3; see conv3x3_halo.hip)
 };
-int vt_conv3x3_halo_tiles(int H, int W, int Cout, int fused_norm);   // GroupNorm partials per image the epilogue writes
+// GroupNorm partials per image the epilogue of this (Cout, input mode xt 0..2, occ2 mode, fused shortcut) launch writes
+int vt_conv3x3_halo_tiles(int H, int W, int Cout, int xt, int occ2, int has_sc);
+int vt_conv3x3_halo_tiles_max(int H, int W);       // upper bound over the variants (buffer sizing)
 int vt_conv_gemm_ptiles(int HWo, int Cout);        // upper bound over configurations (buffer sizing)
 int vt_conv_gemm_ptiles_of(const ConvGemmArgs& a);  // of this launch (GroupNorm partials per image its epilogue writes)
 bool vt_conv3x3_halo_supported(int Cin, int Cout);
-void vt_conv3x3_halo_set_occ2(int on);   // 128-cout layers: 2-workgroups-per-CU tile (default on)
-int vt_conv3x3_halo_occ2(void);
 int vt_conv3x3_halo_config(const Conv3x3Args& a);
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s);
 hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w_ohwi, bf16_t* wp, int Cin, int Cout, hipStream_t s);
@@ -118,7 +119,7 @@ hipError_t vt_launch_gn_stats(const void* x, int x_dtype, int B, int HW, int C, 
                               float* partial, int* nchunks_out, hipStream_t s);
 hipError_t vt_launch_gn_finalize(const float* partial /*[B][nparts][groups][3]*/, int nparts, int B, int C, int groups,
                                  float eps, const float* gamma, const float* beta, float* scale_shift /*[B][C][2]*/,
-                                 hipStream_t s);
+                                 hipStream_t s, int* status = nullptr /* device word: bit 0 raised on non-finite statistics */);
 int vt_gn_max_chunks(int HW, int C);
 // y = act(x*scale + shift) -> bf16 rows
 hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shift, bf16_t* y, int B, int HW,

@@ -122,6 +122,15 @@ class MultiLabelEvaluator:
                     fh.write(f"{name},{v['precision']},{v['recall']},{v['f1']},{v['ap']},{v['support']}\n")
 
 
+def _check_status(model):
+    """After the batch's host copy (a synchronisation point anyway): the encoder's sticky health word (vt_status)."""
+    vae = getattr(model, "vae", model)
+    ctx = vae._context() if hasattr(vae, "_context") else None
+    if ctx is not None and ctx.status():
+        raise FloatingPointError("non-finite activations in the encoder: the fp16 residual-stream storage overflowed "
+                                 "(vt_set_flag(ctx, 4, 0) stores it as fp32) or the checkpoint holds inf / NaN")
+
+
 def _probabilities(model, decoder, loader, device):
     """The batched hot path: encode -> decoder -> sigmoid on the GPU; one host copy of the probabilities per batch."""
     probs, labels = [], []
@@ -130,6 +139,7 @@ def _probabilities(model, decoder, loader, device):
             lat = model.encode(batch["pixel_values"].to(device))
             probs.append(torch.sigmoid(decoder(lat)).cpu().numpy())
             labels.append(MultiLabelEvaluator._np(batch["labels"]))
+            _check_status(model)
     return np.vstack(probs), np.vstack(labels)
 
 

@@ -74,17 +74,12 @@ def load_models(args, device="cuda"):
     return vae_model, decoder, tags_df["name"].tolist()
 
 
-def _require_finite(a, what):
-    """The residual stream and the attention scores are stored as fp16 on the device: activations beyond +-65504 (not seen
-    with PyTorch-init weights) would surface here as inf/nan instead of as silently wrong tags."""
-    import numpy as np
-    if not np.isfinite(a).all():
-        raise FloatingPointError(f"non-finite {what}: activations left the fp16 range of the residual stream; "
-                                 "rerun with fp32 storage (vt_set_flag(ctx, 4, 0))")
+TOP_K = 64          # (confidence, tag) pairs fetched per image with the summary; images with more tags above the threshold fetch their prefix
 
 
 def summarize(conf_row, idx_row, tag_names, threshold):
-    """One image's JSON entry from its sorted confidences / indices (infer_full.py:106-125)."""
+    """One image's JSON entry from its sorted confidences / indices on the host (infer_full.py:106-125) -- the reference
+    formulation; the CLI uses `summarize_batch`, which takes the same numbers from the device-side summary."""
     predicted = []
     for c, i in zip(conf_row, idx_row):
         c = float(c)
@@ -95,6 +90,26 @@ def summarize(conf_row, idx_row, tag_names, threshold):
     return {"predicted_tags": predicted, "total_tags_above_threshold": len(predicted),
             "max_confidence": float(f"{float(conf_row[0]):.4f}"),
             "avg_confidence_top5": float(f"{sum(top5) / 5:.4f}")}      # always divides by 5, like the reference
+
+
+def summarize_batch(pipe, conf, idx, tag_names, threshold, top_k=TOP_K):
+    """conf / idx: sorted device tensors [B,N] (pipe.tag).  Threshold count, top-k, max and top-5 mean come from the
+    device (vt_summarize_confidence): formatting only on the host.  Raises FloatingPointError on non-finite confidences."""
+    top_conf, top_idx, stats = pipe.summarize(conf, idx, threshold, top_k)
+    out = []
+    for b in range(conf.shape[0]):
+        count, mx, avg5, bad = int(stats[b, 0]), float(stats[b, 1]), float(stats[b, 2]), int(stats[b, 3])
+        if bad:
+            raise FloatingPointError(f"{bad} non-finite confidences: activations left the fp16 range of the residual stream "
+                                     "or the checkpoint holds inf / NaN")
+        if count <= top_conf.shape[1]:
+            cs, ix = top_conf[b, :count], top_idx[b, :count]
+        else:                                       # rare: more tags above the threshold than the summary carries
+            cs, ix = conf[b, :count].cpu().numpy(), idx[b, :count].cpu().numpy()
+        predicted = [{"tag": tag_names[int(i)], "confidence": float(f"{float(c):.4f}")} for c, i in zip(cs, ix)]
+        out.append({"predicted_tags": predicted, "total_tags_above_threshold": count,
+                    "max_confidence": float(f"{mx:.4f}"), "avg_confidence_top5": float(f"{avg5:.4f}")})
+    return out
 
 
 def infer_and_classify(args):
@@ -130,10 +145,15 @@ def infer_and_classify(args):
         try:
             x = torch.stack(batch).to(device)
             conf, idx = pipe.tag(x)
-            conf, idx = conf.cpu().numpy(), idx.cpu().numpy()
-            _require_finite(conf, "confidences")
-            for k, p in enumerate(names):
-                results[str(p)] = summarize(conf[k], idx[k], tag_names, args.confidence_threshold)
+            if pipe.status():
+                # an activation left the fp16 range of the residual-stream storage: keep fp32 storage from here on
+                print("警告: 激活值超出fp16范围，改用fp32残差存储重新计算该批次")
+                pipe.set_fp32_residual(True)
+                conf, idx = pipe.tag(x)
+                if pipe.status():
+                    raise FloatingPointError("non-finite activations even with fp32 residual storage (inf / NaN weights?)")
+            for p, entry in zip(names, summarize_batch(pipe, conf, idx, tag_names, args.confidence_threshold)):
+                results[str(p)] = entry
                 processed += 1
         except Exception as e:  # noqa: BLE001
             errors += len(names)

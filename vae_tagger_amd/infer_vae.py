@@ -55,10 +55,17 @@ def infer_and_save_latents(args):
         if not batch:
             continue
         try:
-            latent = vae_model.encode(torch.stack(batch).to(device))
+            x = torch.stack(batch).to(device)
+            latent = vae_model.encode(x)
             flat = latent.reshape(latent.size(0), -1).cpu().numpy()
-            from .infer_full import _require_finite
-            _require_finite(flat, "latents")
+            ctx = vae_model.vae._context()
+            if ctx.status():
+                # an activation left the fp16 range of the residual-stream storage: keep fp32 storage from here on
+                print("警告: 激活值超出fp16范围，改用fp32残差存储重新计算该批次")
+                ctx.call("vt_set_flag", 4, 0)
+                flat = vae_model.encode(x).reshape(latent.size(0), -1).cpu().numpy()
+                if ctx.status():
+                    raise FloatingPointError("non-finite activations even with fp32 residual storage (inf / NaN weights?)")
             for k, p in enumerate(names):
                 latent_data[str(p)] = flat[k].tolist()
                 processed += 1

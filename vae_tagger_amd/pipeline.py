@@ -63,6 +63,31 @@ class EncodeTagPipeline:
         return conf, idx
 
     @torch.no_grad()
+    def summarize(self, conf, idx, threshold, top_k=64):
+        """Device-side counterpart of the per-image loop of infer_full.py:106-125 on sorted (conf, idx): returns host arrays
+        (top_conf [B,K] fp32, top_idx [B,K] int32, stats [B,4] = count >= threshold, max, top-5 sum / 5, non-finite count)
+        from ONE small copy -- B x (2K + 4) values instead of the B x N x 12 bytes of the full sorted arrays."""
+        B, N = conf.shape
+        K = int(max(5, min(top_k, N)))
+        tc = torch.empty(B, K, dtype=torch.float32, device=conf.device)
+        ti = torch.empty(B, K, dtype=torch.int32, device=conf.device)
+        st = torch.empty(B, 4, dtype=torch.float32, device=conf.device)
+        self.ctx.call("vt_summarize_confidence", vp(conf), vp(idx), B, N, float(threshold), K, vp(tc), vp(ti), vp(st),
+                      stream_ptr(conf.device))
+        packed = torch.cat([tc, ti.view(torch.float32), st], dim=1).cpu()           # one D2H copy
+        return (packed[:, :K].numpy(), packed[:, K:2 * K].contiguous().view(torch.int32).numpy(), packed[:, 2 * K:].numpy())
+
+    def status(self, clear=True):
+        """Sticky health word of the context (synchronises): non-zero = non-finite GroupNorm statistics were seen, i.e. an
+        activation left the fp16 range of the residual-stream storage (or the weights hold inf / NaN)."""
+        return self.ctx.status(clear, stream_ptr(self.device))
+
+    def set_fp32_residual(self, on=True):
+        """Store the residual stream as fp32 (and conv1 outputs as bf16) instead of fp16: for checkpoints whose activations
+        exceed +-65504 (about 7 % slower)."""
+        self.ctx.call("vt_set_flag", 4, 0 if on else 1)
+
+    @torch.no_grad()
     def normalize_u8(self, u8_hwc):
         """ToTensor + Normalize(0.5, 0.5) on the device: uint8 [B,H,W,3] -> fp32 NCHW in [-1,1] (modules.py:136-140).
         Uploading uint8 moves 4x fewer bytes over PCIe than the fp32 tensor the reference builds on the CPU."""
