@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (not the 2:1-sparse headline)
+MFMA_FP8_DENSE_PEAK_TFLOPS = 5000.0      # MI355X_MICROARCH.md: ~5 PF dense fp8 (block-scaled f8f6f4 MFMA)
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -43,6 +44,9 @@ def parse():
     p.add_argument("--bucketed", action="store_true",
                    help="BASELINE configs[3]: same-shape batches drawn from the reference's 512..1024 step-64 aspect buckets")
     p.add_argument("--bucket-batch", type=int, default=8, help="images per same-shape batch in --bucketed mode")
+    p.add_argument("--fp8", action="store_true",
+                   help="BASELINE configs[4]: the stride-1 3x3 resnet convs on fp8 (e4m3) operands / fp8 MFMA (vt_set_flag 11); opt-in mode, "
+                        "logits within 1e-2 of the CPU reference, latents ~1e-1")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--generic-conv", action="store_true", help="A/B: disable the halo-tile 3x3 kernel")
     p.add_argument("--no-occ2", action="store_true", help="A/B: 128-cout convs on the one-workgroup-per-CU tile")
@@ -181,6 +185,9 @@ def main():
         pipe.ctx.call("vt_set_flag", 0, 0)
     if a.no_occ2:
         pipe.ctx.call("vt_set_flag", 3, 0)      # one workgroup per CU for every halo conv
+    if a.fp8:
+        pipe.ctx.call("vt_set_flag", 11, 1)
+        vae._context().call("vt_set_flag", 11, 1)
     for fv in a.flag:
         f, v = fv.split("=")
         pipe.ctx.call("vt_set_flag", int(f), int(v))
@@ -286,20 +293,22 @@ def main():
                 launches[i] = 0; tot_ms[i] = 0.0; tot_fl[i] = 0.0
         dom = max(range(nm), key=lambda i: tot_ms[i])
         achieved = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
+        dom_peak = MFMA_FP8_DENSE_PEAK_TFLOPS if b"fp8" in names[dom] else MFMA_BF16_DENSE_PEAK_TFLOPS
         gemm_ms = sum(tot_ms[i] for i in range(nm))
         gn_gbs = tot_fl[nm] / (tot_ms[nm] * 1e-3) / 1e9 if tot_ms[nm] > 0 else 0.0
         traffic, traffic_src = (None, None) if (a.bucketed or a.encode_only) else pmc_traffic(names[dom].decode(), B, a.height, a.width)
         res = {
             "metric": ("images/sec encode+tag, bucketed 512..1024 bf16" if a.bucketed else
-                       "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16"),
+                       "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16").replace(
+                           "bf16", "fp8 (3x3 resnet convs; rest bf16)" if a.fp8 else "bf16"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_step_without_events": round(elapsed_plain / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": (f"configs[3]: bucketed 512->1024 step 64 (67 reachable buckets), {2 * world} same-shape batches of "
                                     f"{a.bucket_batch} per step, FLUX-VAE encode + 8-head attention decoder, {a.tags} tags"
                                     if a.bucketed else
-                                    ("configs[2]: " if not a.encode_only else "configs[1]: ")
+                                    ("configs[4] (per GPU): " if a.fp8 else "configs[2]: " if not a.encode_only else "configs[1]: ")
                                     + f"batch {B}/GPU {a.width}x{a.height} FLUX-VAE encode"
                                     + ("" if a.encode_only else f" + 8-head attention decoder, {a.tags} tags"))
                        + ", random-init weights (seeded), fp32 NCHW input resident in HBM",
@@ -308,8 +317,8 @@ def main():
                        "end_to_end_tflops_per_gpu": round(ips / world * flops_img / 1e12, 2),
                        "end_to_end_frac_of_mfma_peak": round(ips / world * flops_img / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": names[dom].decode(), "achieved": round(achieved, 2),
-                         "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                         "peak": dom_peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / dom_peak, 4),
                          "traffic": None if traffic is None else round(traffic), "traffic_unit": "bytes per launch (mean)",
                          "traffic_source": traffic_src,
                          "launches": int(launches[dom]),

@@ -135,6 +135,10 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         registers, keys streamed through LDS, row sums in registers); 0 = the generic GEMM with the exp epilogue.
  * flag 10: 1 (default) = P.V reads the probabilities (4+ GB per launch, read once) with the streaming (nt) cache policy so they
  *         do not displace the rest of the working set from L2 / Infinity Cache; 0 = default policy.
+ * flag 11: 1 = BASELINE.json configs[4]: the 20 stride-1 3x3 resnet convolutions run on fp8 (OCP e4m3) operands on the fp8 MFMA
+ *         (v_mfma_scale_f32_32x32x64_f8f6f4, 2x the bf16 rate): weights e4m3 with per-output-channel scales, activations e4m3(8 x)
+ *         written by the GroupNorm-apply pass; fp32 accumulate, everything else unchanged.  OPT-IN, for tagging only: latents move
+ *         by ~1e-1 (max; rms 2e-2), logits stay within 1e-2 of the CPU reference (tests/diagnostics/fp8_study.py).  0 (default) = bf16.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 
@@ -170,6 +174,11 @@ int vt_op_conv2d_gn(vt_context* ctx, const void* x_bf16_nhwc, const void* w_bf16
                     const float* residual_f32, float* out_f32, void* out_bf16, int B, int Hin, int Win, int Cin,
                     int Cout, int ksize, int stride, int pad_lo, int pad_hi, int groups, float eps, const float* gamma,
                     const float* beta, float* scale_shift_out, void* workspace, void* stream);
+/* the fp8 conv of flag 11 as a single operator: x fp32 NHWC and w fp32 OIHW (both on the device) are quantised exactly as the
+ * encoder quantises them (x -> e4m3(8 x), w -> e4m3 with per-cout absmax scales); out fp32 NHWC.  Cin % 64 == 0, Cout % 128 == 0. */
+size_t vt_op_conv3x3_fp8_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int vt_op_conv3x3_fp8(vt_context* ctx, const float* x_f32_nhwc, const float* w_f32_oihw, const float* bias, const float* residual_f32,
+                      float* out_f32, int B, int H, int W, int Cin, int Cout, void* workspace, void* stream);
 int vt_op_gemm_nt(vt_context* ctx, const void* a_bf16, const void* b_bf16, const float* bias, float* out_f32,
                   void* out_bf16, int batch, int M, int N, int K, int lda, int ldb, int ldo, long long a_bs,
                   long long b_bs, long long o_bs, float alpha, int bias_per_row, void* stream);

@@ -192,3 +192,44 @@ def test_softmax_rows(ops, rows, n):
     got = ops.softmax_rows(s)
     assert got.shape[1] % 8 == 0 and torch.all(got[:, n:] == 0)
     assert torch.allclose(got[:, :n], ref, rtol=1e-2, atol=1e-6)
+
+
+def _e4m3(t):
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+FP8_CASES = [
+    # B, Cin, Cout, H, W
+    (2, 128, 128, 40, 72),       # ragged 8x32 tiles on both edges, two channel chunks
+    (1, 64, 256, 16, 32),        # one chunk (last-chunk path only), two cout tiles
+    (1, 256, 128, 33, 35),       # odd sizes, four chunks
+    (2, 512, 512, 9, 13),        # image smaller than a tile, eight chunks, four cout tiles
+    (1, 128, 128, 64, 64),       # whole tiles only
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", FP8_CASES)
+def test_fp8_conv_matches_torch_on_the_same_quantised_operands(ops, B, Cin, Cout, H, W):
+    """conv3x3_halo_fp8.hip (BASELINE configs[4], vt_set_flag 11): activations e4m3(8 x), weights e4m3 with per-cout absmax
+    scales, fp32 accumulate.  Reference = torch fp32 conv of the SAME quantised operands (torch's own float8_e4m3fn
+    conversion): what is left is accumulation-order noise, so fragment layout, swizzle and tap order are all pinned."""
+    x = _rand((B, Cin, H, W), 1)
+    x[0, :, 0, 0] = 0.001                       # e4m3 subnormals of 8 x
+    w = _rand((Cout, Cin, 3, 3), 2, (Cin * 9) ** -0.5)
+    b = _rand((Cout,), 3, 0.1)
+    sc = w.abs().amax(dim=(1, 2, 3), keepdim=True) / 448.0
+    wq = _e4m3(w / sc) * sc
+
+    def ref_of(xx):
+        return F.conv2d(_e4m3(xx * 8.0) / 8.0, wq, None, padding=1)
+    # the matrix pipe sums the 64 products of a block in a fixed-point-like adder aligned to the largest one (measured here:
+    # ~1e-5 of the output scale on ordinary data, ~1e-4 of the largest product): far below e4m3's 2^-4, far above fp32 noise
+    res = _rand((B, Cout, H, W), 4)
+    got = ops.conv3x3_fp8(x, w, b, residual_nchw=res)
+    ref = ref_of(x) + b.view(1, -1, 1, 1) + res
+    assert torch.allclose(got, ref, rtol=1e-4, atol=3e-4), (got - ref).abs().max()
+    got = ops.conv3x3_fp8(x, w)
+    assert torch.allclose(got, ref_of(x), rtol=1e-4, atol=3e-4)
+    x[0, 0, 1, 1] = 100.0                       # saturates at 448 / 8: the clamp is part of the contract
+    got = ops.conv3x3_fp8(x, w)
+    assert torch.allclose(got, ref_of(x), rtol=1e-4, atol=3e-3), (got - ref_of(x)).abs().max()

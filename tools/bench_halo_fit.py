@@ -28,14 +28,24 @@ def run(B, H, W, Cin, Cout, occ2, out="bf16", iters=10):
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * B * H * W * Cout * 9 * Cin
     rows = 16 if (Cout % 256 == 0 or occ2) else 32
-    tiles = B * (H // rows) * (W // 16) * (Cout // (256 if Cout % 256 == 0 else 128))
-    per_cu = tiles / 256.0 / (2 if (Cout % 256 and occ2) else 1)
+    bc = 128 if (occ2 == 3 or Cout % 256) else 256
+    tiles = B * (H // rows) * (W // 16) * (Cout // bc)
+    per_cu = tiles / 256.0 / (2 if (occ2 == 3 or (Cout % 256 and occ2)) else 1)
     us_tile = ms * 1e3 / per_cu
     print(f"B{B} {H}x{W} {Cin:4d}->{Cout} occ2={occ2} {out}: {ms:7.3f} ms {fl/ms/1e9:7.1f} TF/s  nk={Cin//32*9:4d} tiles/CU-slot {per_cu:6.1f}  us/tile {us_tile:7.2f}", flush=True)
     return us_tile
-for Cout, shape in ((256, (16, 512, 512)), (128, (8, 1024, 1024))):
-    for occ2 in ((0, 1) if Cout == 128 else (0,)):
-        for Cin in (64, 128, 256, 512, 1024):
+import numpy as np
+for Cout, shape in ((128, (8, 1024, 1024)), (256, (16, 512, 512))):
+    for occ2 in (3, 0):
+        pts = []
+        for Cin in (32, 64, 128, 256, 512, 1024):
             print(f"occ2 {occ2}: ", end="")
-            run(shape[0], shape[1], shape[2], Cin, Cout, occ2, iters=5)
+            pts.append((Cin // 32 * 9, run(shape[0], shape[1], shape[2], Cin, Cout, occ2, iters=5)))
+        # least-squares fit us/tile-slot = overhead + nk * step over the four largest K
+        A = np.array([[1.0, p[0]] for p in pts[2:]]); y = np.array([p[1] for p in pts[2:]])
+        (ov, st), *_ = np.linalg.lstsq(A, y, rcond=None)
+        bc = 128 if (occ2 == 3 or Cout % 256) else 256
+        slots = 2 if occ2 == 3 or (Cout % 256 and occ2) else 1
+        print(f"   fit Cout {Cout} occ2 {occ2}: overhead {ov:6.2f} us/tile-slot, step {st:6.3f} us  (tile {bc} couts, {slots} slot(s)/CU: "
+              f"{256 * bc * 32 * 2 / st / 1e6 * slots * 256 / 1e6:6.1f} TF/s asymptotic)", flush=True)
 ctx.call("vt_set_flag", 3, 3)

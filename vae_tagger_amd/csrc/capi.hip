@@ -22,7 +22,10 @@ struct HostTensor {
     int64_t numel() const { int64_t n = 1; for (auto d : shape) n *= d; return n; }
 };
 
-struct ConvW { const bf16_t* w = nullptr; const bf16_t* wp = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0; };   // w: [cout][tap][cin]; wp: halo-kernel packing
+struct ConvW {
+    const bf16_t* w = nullptr; const bf16_t* wp = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0;   // w: [cout][tap][cin]; wp: halo-kernel packing
+    const unsigned char* wp8 = nullptr; const float* mult8 = nullptr;   // fp8 halo kernel: e4m3 weights / per-cout (scale / act_scale)
+};
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
 struct ResnetW {
     NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0;
@@ -67,6 +70,39 @@ float h2f(uint16_t h) {
     float f; memcpy(&f, &u, 4); return f;
 }
 
+// float -> OCP e4m3fn (1-4-3, bias 7, max 448, no infinities), round to nearest even, saturating
+uint8_t f2e4m3(float f) {
+    if (f != f) return 0x7f;
+    const uint8_t sgn = signbit(f) ? 0x80 : 0x00;
+    const float a = fabsf(f);
+    if (a >= 448.f) return sgn | 0x7e;
+    if (a < 0.015625f) return sgn | (uint8_t)nearbyintf(a * 512.f);       // subnormals: multiples of 2^-9 (8 -> the smallest normal)
+    int e;
+    const float m = frexpf(a, &e);                                          // a = m 2^e, m in [0.5, 1)
+    int M = (int)nearbyintf((2.f * m - 1.f) * 8.f), E = e - 1;
+    if (M == 8) { M = 0; ++E; }
+    const int biased = E + 7;
+    if (biased > 15 || (biased == 15 && M > 6)) return sgn | 0x7e;
+    return sgn | (uint8_t)((biased << 3) | M);
+}
+constexpr float FP8_ACT_SCALE = 8.0f;      // activations are stored as e4m3(8 x): |silu(GroupNorm)| up to 56 before saturation
+
+// e4m3 packing of a 3x3 conv for conv3x3_halo_fp8.hip: Wp8[cin/64][step (kx-major)][cout row][64] + mult[cout] = scale / act_scale
+void pack_conv_fp8(const float* w_oihw, int cout, int cin, std::vector<uint8_t>* wp8, std::vector<float>* mult) {
+    wp8->assign((size_t)cout * 9 * cin, 0);
+    mult->resize(cout);
+    for (int o = 0; o < cout; ++o) {
+        float amax = 0.f;
+        for (size_t i = 0; i < (size_t)cin * 9; ++i) amax = fmaxf(amax, fabsf(w_oihw[(size_t)o * cin * 9 + i]));
+        const float sc = amax > 0.f ? amax / 448.f : 1.f;
+        (*mult)[o] = sc / FP8_ACT_SCALE;
+        const int row = (o & ~31) + vt_halo_fp8_row_of_cout(o & 31);
+        for (int i = 0; i < cin; ++i)
+            for (int t = 0; t < 9; ++t)
+                (*wp8)[(((size_t)(i >> 6) * 9 + vt_halo_step_of_tap(t)) * cout + row) * 64 + (i & 63)] = f2e4m3(w_oihw[((size_t)o * cin + i) * 9 + t] / sc);
+    }
+}
+
 constexpr size_t ALIGN = 256;
 size_t align_up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
 
@@ -91,6 +127,7 @@ struct vt_context {
     int fuse_shortcut = 1;          // vt_set_flag(ctx, 8, v): resnet conv_shortcut inside conv2's launch
     int pv_stream = 1;              // vt_set_flag(ctx, 10, v): P.V reads P (4+ GB, read once) with the streaming cache policy
     int attn_qk_kernel = 1;         // vt_set_flag(ctx, 9, v): dedicated Q.K^T kernel (attn_qk.hip) instead of the generic GEMM
+    int fp8 = 0;                    // vt_set_flag(ctx, 11, v): stride-1 3x3 resnet convs on fp8 (e4m3) operands (BASELINE configs[4])
     int halo_occ2 = 3;              // vt_set_flag(ctx, 3, v): two-workgroups-per-CU tile mode of the halo conv
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
     // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
@@ -178,6 +215,13 @@ int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, C
                     hp[(((size_t)(i >> 5) * 9 + vt_halo_step_of_tap(t)) * cout + ((o & ~63) + vt_halo_row_of_cout(o & 63))) * 32 + (i & 31)] = p[((size_t)o * 9 + t) * cin + i];
         out->wp = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
         if (!out->wp) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+    }
+    if (k == 3 && vt_conv3x3_halo_fp8_supported(cin, cout)) {
+        std::vector<uint8_t> p8; std::vector<float> m8;
+        pack_conv_fp8(w->v.data(), cout, cin, &p8, &m8);
+        out->wp8 = (const unsigned char*)c->upload(p8.data(), p8.size());
+        out->mult8 = (const float*)c->upload(m8.data(), m8.size() * 4);
+        if (!out->wp8 || !out->mult8) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
     }
     return VT_OK;
 }
@@ -290,6 +334,23 @@ hipError_t launch_halo(vt_context* c, const Conv3x3Args& a_in, hipStream_t s) {
     return hipSuccess;
 }
 
+hipError_t launch_halo_fp8(vt_context* c, const Conv3x3Fp8Args& a, hipStream_t s) {
+    if (!c->profiling) return vt_launch_conv3x3_halo_fp8(a, s);
+    vt_context::ProfRec r;
+    r.e0 = c->next_event(); r.e1 = c->next_event();
+    if (!r.e0 || !r.e1) return hipErrorOutOfMemory;
+    r.flops = 2.0 * a.batch * (double)a.H * a.W * a.Cout * 9.0 * a.Cin;
+    r.cfg = VT_PROF_HALO_FP8;
+    hipError_t e = hipEventRecord(r.e0, s);
+    if (e != hipSuccess) return e;
+    e = vt_launch_conv3x3_halo_fp8(a, s);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(r.e1, s);
+    if (e != hipSuccess) return e;
+    c->prof.push_back(r);
+    return hipSuccess;
+}
+
 // GroupNorm bookkeeping: `partial` holds (n, mean, M2) triples for the tensor that will be normalised next,
 // written either by the producing conv's epilogue (stats_parts > 0) or by the standalone stats pass.
 struct GnState {
@@ -299,7 +360,8 @@ struct GnState {
 
 // y = act(GroupNorm(x)) as bf16 rows.  Uses epilogue-produced partials when present.
 int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int B, int HW, const NormW& n, int groups, int silu, bf16_t* y,
-           GnState& g, hipStream_t s) {
+           GnState& g, hipStream_t s, bool out_fp8 = false) {
+    const float o8 = out_fp8 ? FP8_ACT_SCALE : 0.f;       // y then holds e4m3(8 y), one byte per element
     int parts = g.parts;
     if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, xdt, B, HW, n.c, groups, g.partial, &parts, s), "gn_stats");
     g.parts = 0;
@@ -308,15 +370,15 @@ int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int
         vt_context::ProfRec r;
         r.e0 = c->next_event(); r.e1 = c->next_event();
         if (!r.e0 || !r.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
-        r.flops = (double)B * HW * n.c * (xdt == 1 ? 6.0 : 4.0);     // algorithmic bytes: one read + one bf16 write
+        r.flops = (double)B * HW * n.c * ((xdt == 1 ? 4.0 : 2.0) + (out_fp8 ? 1.0 : 2.0));     // algorithmic bytes: one read + one bf16 / fp8 write
         r.cfg = VT_PROF_GN_APPLY;
         HIPCK(c, hipEventRecord(r.e0, s), "hipEventRecord");
-        HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s), "gn_apply");
+        HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s, o8), "gn_apply");
         HIPCK(c, hipEventRecord(r.e1, s), "hipEventRecord");
         c->prof.push_back(r);
         return VT_OK;
     }
-    HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s), "gn_apply");
+    HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s, o8), "gn_apply");
     return VT_OK;
 }
 
@@ -328,7 +390,8 @@ int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int
 struct ScFuse { const bf16_t* x; const bf16_t* wp; const float* bias; int cin; };
 int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int Win, int stride, int pad, int Hout,
              int Wout, const void* res, void* oh, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32,
-             const float* xnorm_f32 = nullptr, const float* ss = nullptr, int rdt = 1, const ScFuse* sc = nullptr) {
+             const float* xnorm_f32 = nullptr, const float* ss = nullptr, int rdt = 1, const ScFuse* sc = nullptr,
+             bool x_fp8 = false) {
     const float* res32 = rdt == 1 ? (const float*)res : nullptr;
     const f16_t* res16 = rdt == 2 ? (const f16_t*)res : nullptr;
     float* o32 = rdt == 1 ? (float*)oh : nullptr;
@@ -336,6 +399,16 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     const int cpg = w.cout / groups;
     const bool fuse = gn && c->fuse_gn_stats && (cpg == 4 || cpg == 8 || cpg == 16);
     if (gn) gn->parts = 0;
+    if (x_fp8) {
+        if (!w.wp8 || w.k != 3 || stride != 1 || pad != 1 || ss || sc) return c->fail(VT_ERR_STATE, "internal: fp8 operands requested for a conv the fp8 kernel cannot run");
+        Conv3x3Fp8Args h{};
+        h.X = (const unsigned char*)x; h.Wp = w.wp8; h.mult = w.mult8; h.bias = w.b; h.res = res32; h.res_f16 = res16;
+        h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
+        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
+        if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_fp8_tiles(Hin, Win); }
+        HIPCK(c, launch_halo_fp8(c, h, s), "conv3x3_halo_fp8");
+        return VT_OK;
+    }
     if (c->use_halo_conv && w.wp && w.k == 3 && stride == 1 && pad == 1 && Hout == Hin && Wout == Win) {
         Conv3x3Args h{};
         h.X = xnorm_f32 ? nullptr : x; h.Xf32 = xnorm_f32; h.scale_shift = ss;
@@ -373,10 +446,11 @@ bool norm_conv_fusable(const vt_context* c, const ConvW& w, int cin) {
 int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, int xdt, int B, int H, int W,
                   int groups, bf16_t* act, const void* res, void* oh, bf16_t* o16, GnState& gn, bool want_stats,
                   hipStream_t s, int rdt, const ScFuse* sc = nullptr) {
-    if (xdt == 2 || !norm_conv_fusable(c, w, n.c)) {          // (the fused staging reads fp32 or bf16 only)
-        int r = run_gn(c, x, xdt, B, H * W, n, groups, 1, act, gn, s);
+    const bool f8 = c->fp8 && w.wp8 && w.k == 3 && !sc;      // fp8 operands: the GroupNorm-apply pass writes e4m3, the conv reads it
+    if (f8 || xdt == 2 || !norm_conv_fusable(c, w, n.c)) {   // (the fused staging reads fp32 or bf16 only)
+        int r = run_gn(c, x, xdt, B, H * W, n, groups, 1, act, gn, s, f8);
         if (r) return r;
-        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt, sc);
+        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt, sc, f8);
     }
     if (sc) return c->fail(VT_ERR_STATE, "internal: fused shortcut with the fused-norm staging");
     int parts = gn.parts;
@@ -566,6 +640,8 @@ EncPlan plan_encoder(const EncoderW& e, int B, int H, int W) {
         if (t3 > ck) ck = t3;
         const int t4 = vt_conv_in_mfma_parts(hh, ww);
         if (t4 > ck) ck = t4;
+        const int t5 = vt_conv3x3_halo_fp8_tiles(hh, ww);
+        if (t5 > ck) ck = t5;
         if (t1 > ck) ck = t1;
         if (t2 > ck) ck = t2;
         if (ck > p.max_chunks) p.max_chunks = ck;
@@ -805,7 +881,8 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
         gn.parts = fuse0 ? parts : 0;
     }
 
-    auto fuse_sc = [&](const ResnetW& rw) { return c->fuse_shortcut && rw.sc_wp && c->use_halo_conv && rw.c2.wp && !c->fuse_gn_apply; };
+    // (the fp8 kernel has no fused-shortcut K-steps: with fp8 operands the shortcut is its own GEMM launch)
+    auto fuse_sc = [&](const ResnetW& rw) { return c->fuse_shortcut && rw.sc_wp && c->use_halo_conv && rw.c2.wp && !c->fuse_gn_apply && !(c->fp8 && rw.c2.wp8); };
     // one ResnetBlock2D: h <- conv2(silu(gn(conv1(silu(gn(h)))))) + shortcut(h)
     auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out) -> int {
         const int nxt = (cur + 1) % 3, scb = (cur + 2) % 3;
@@ -1074,6 +1151,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 8) { c->fuse_shortcut = value != 0; return VT_OK; }
     if (flag == 9) { c->attn_qk_kernel = value != 0; return VT_OK; }
     if (flag == 10) { c->pv_stream = value != 0; return VT_OK; }
+    if (flag == 11) { c->fp8 = value != 0; return VT_OK; }
     if (flag == 7) {
         if (value < 0 || value > 2) return c->fail(VT_ERR_INVALID, "vt_set_flag(7): value %d not in 0..2", value);
         c->attn_mode = value;
@@ -1320,6 +1398,42 @@ int vt_op_conv2d_gn(vt_context* c, const void* x, const void* w, const float* bi
     if (r) return r;
     if (gn.parts == 0) return c->fail(VT_ERR_INVALID, "vt_op_conv2d_gn: this shape has no stats epilogue");
     HIPCK(c, vt_launch_gn_finalize(gn.partial, gn.parts, B, Cout, groups, eps, gamma, beta, scale_shift, s), "gn_finalize");
+    return VT_OK;
+}
+
+size_t vt_op_conv3x3_fp8_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || !vt_conv3x3_halo_fp8_supported(Cin, Cout)) return 0;
+    return align_up((size_t)B * H * W * Cin) + align_up((size_t)B * Cin * 8) + align_up((size_t)Cout * 9 * Cin) + align_up((size_t)Cout * 4) + ALIGN;
+}
+
+// 3x3 stride-1 pad-1 conv on fp8 operands, as the encoder runs it with vt_set_flag(ctx, 11, 1): x (fp32 NHWC, device) is quantised
+// to e4m3(8 x) by the GroupNorm-apply kernel (identity affine, no SiLU), w (fp32 OIHW, DEVICE; copied to the host, packed to e4m3
+// with per-cout scales and written into the workspace: synchronises).  out = conv(deq(x8), deq(w8)) + bias (+ residual), fp32 NHWC.
+int vt_op_conv3x3_fp8(vt_context* c, const float* x_nhwc, const float* w_oihw, const float* bias, const float* res, float* o32,
+                      int B, int H, int W, int Cin, int Cout, void* ws, void* stream) {
+    if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
+    if (!x_nhwc || !w_oihw || !o32 || !ws || ((uintptr_t)ws % ALIGN)) return c->fail(VT_ERR_INVALID, "vt_op_conv3x3_fp8: bad buffer");
+    if (vt_op_conv3x3_fp8_workspace_bytes(B, H, W, Cin, Cout) == 0) return c->fail(VT_ERR_INVALID, "vt_op_conv3x3_fp8: unsupported shape");
+    hipStream_t s = (hipStream_t)stream;
+    char* p = (char*)ws;
+    unsigned char* x8 = (unsigned char*)p; p += align_up((size_t)B * H * W * Cin);
+    float* ss = (float*)p; p += align_up((size_t)B * Cin * 8);
+    unsigned char* w8 = (unsigned char*)p; p += align_up((size_t)Cout * 9 * Cin);
+    float* mult = (float*)p;
+    std::vector<float> hw((size_t)Cout * 9 * Cin), hss((size_t)B * Cin * 2);
+    HIPCK(c, hipMemcpy(hw.data(), w_oihw, hw.size() * 4, hipMemcpyDeviceToHost), "vt_op_conv3x3_fp8 copy");
+    std::vector<uint8_t> p8; std::vector<float> m8;
+    pack_conv_fp8(hw.data(), Cout, Cin, &p8, &m8);
+    for (size_t i = 0; i < hss.size(); i += 2) { hss[i] = 1.f; hss[i + 1] = 0.f; }
+    HIPCK(c, hipMemcpy(w8, p8.data(), p8.size(), hipMemcpyHostToDevice), "vt_op_conv3x3_fp8 copy");
+    HIPCK(c, hipMemcpy(mult, m8.data(), m8.size() * 4, hipMemcpyHostToDevice), "vt_op_conv3x3_fp8 copy");
+    HIPCK(c, hipMemcpy(ss, hss.data(), hss.size() * 4, hipMemcpyHostToDevice), "vt_op_conv3x3_fp8 copy");
+    HIPCK(c, vt_launch_gn_apply(x_nhwc, 1, ss, x8, B, H * W, Cin, 0, s, FP8_ACT_SCALE), "vt_op_conv3x3_fp8 quantise");
+    Conv3x3Fp8Args h{};
+    h.X = x8; h.Wp = w8; h.mult = mult; h.bias = bias; h.res = res; h.out_f32 = o32; h.zeros = c->zeros;
+    h.batch = B; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout;
+    HIPCK(c, launch_halo_fp8(c, h, s), "vt_op_conv3x3_fp8");
     return VT_OK;
 }
 

@@ -137,16 +137,19 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     const int wpw = (WPCS % NLD == 0) ? WPW : (wave < WPCS % NLD ? WPW : WPW - 1);
 
     STAMP(0);
-    // ---- tile coordinates
-    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + ROWS - 1) / ROWS;
-    const int ctiles = a.Cout / BC;
-    const int per_img = tiles_x * tiles_y * ctiles;
+    // ---- tile coordinates.  The divisors are launch constants: the host passes 2^40 / d + 1 multipliers (exact for
+    // n * d < 2^40), so the five runtime integer divisions (~50 instructions each) in front of the first DMA become multiplies.
+    const int tiles_x = a.tiles_x, ctiles = a.ctiles, per_img = a.per_img;
+    auto fdiv = [](int n, unsigned long long m, int d) -> int {
+        return m ? (int)(((unsigned long long)(unsigned)n * m) >> 40) : n / d;
+    };
     int logical = vt_xcd_remap(blockIdx.x, gridDim.x);
-    const int b = logical / per_img;
+    const int b = fdiv(logical, a.m_per_img, per_img);
     logical -= b * per_img;
-    const int ct = logical % ctiles;
-    const int tile = logical / ctiles;
-    const int ty0 = (tile / tiles_x) * ROWS, tx0 = (tile % tiles_x) * TW;
+    const int tile = fdiv(logical, a.m_ctiles, ctiles);
+    const int ct = logical - tile * ctiles;
+    const int tyi = fdiv(tile, a.m_tiles_x, tiles_x);
+    const int ty0 = tyi * ROWS, tx0 = (tile - tyi * tiles_x) * TW;
     const int c0 = ct * BC;
 
     const long long img = (long long)b * a.H * a.W * a.Cin;
@@ -247,8 +250,34 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
         }
     };
 
-    // ---- fragment addressing
+    // ---- prologue: X(0), then W(0..NW-2).  Plain-input tiles issue their DMA before anything else is set up: the
+    // fragment addresses and the bias loads that initialise the accumulators run under the DMA latency (~2 us per tile).
+    // SPF (software-pipelined fragments, XT == 0): the MFMA operands of step t+1 are read from LDS DURING step t
+    // (each X fragment is refilled as soon as its last MFMA has issued; the W fragments, live until the last MFMA,
+    // are refilled at the end of the step and fly during the barrier wait), so after a barrier the matrix pipe
+    // starts at once instead of waiting for 12 ds_read_b128.  That needs W(t+1) landed at the barrier of step t.
+    constexpr bool SPF = XT == 0;
+    // W(t + LEAD) is issued during step t into the stage of W(t-1), whose fragments were read during step t-2: TWO
+    // barriers lie between a stage's last ds_read and the DMA that overwrites it.  (With one barrier -- LEAD = NW --
+    // a ds_read issued before the barrier but still queued in the LDS pipe lost against the returning DMA about once
+    // per 10^5 tiles at two workgroups per CU: s_barrier does not wait for lgkmcnt.)
+    constexpr int LEAD = NW - 1;
+    constexpr int WOUT = SPF ? LEAD - 2 : NW - 2;  // W tiles issued after the one a barrier needs
     const int fr = lane & 15, fq = lane >> 4;
+    // (the bias loads are the oldest vector-memory operations of the wave: every counted wait below covers them)
+    f32x4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        bv[i] = a.bias ? *(const f32x4*)(a.bias + c0 + wc * 64 + 16 * fq + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" ::: "memory");
+    if constexpr (XT == 0) {
+        issue_x_dma(0);
+#pragma unroll
+        for (int t = 0; t < LEAD; ++t)
+            if (t < nk) issue_w(t, t % 9);
+        asm volatile("" ::: "memory");
+    }
+    // ---- fragment addressing
     // W fragment i: row wc*64 + i*16 + fr, swz = ((fr >> 2) & 1) << 1
     const int wfoff = (wc * 64 + fr) * HB + ((fq ^ (((fr >> 2) & 1) << 1)) << 4);
     // X fragment j at tap (dy,dx): halo row hr = R + fr, R = wp*8*18 + (j+dy)*18 + dx (wave-uniform).
@@ -265,15 +294,11 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     f32x4 acc[TC][TP];
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
-        const f32x4 bv = a.bias ? *(const f32x4*)(a.bias + c0 + wc * 64 + 16 * fq + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < TP; ++j) acc[i][j] = bv;
+        for (int j = 0; j < TP; ++j) acc[i][j] = bv[i];
     }
 
-    // ---- prologue: X(0), then W(0..NW-2)
-    if constexpr (XT == 0) {
-        issue_x_dma(0);
-    } else {
+    if constexpr (XT != 0) {
         const float* ssg = a.scale_shift + (long long)b * a.Cin * 2;
         for (int i = threadIdx.x; i < a.Cin * 2; i += NT) ssl[i] = ssg[i];
         __syncthreads();
@@ -285,21 +310,10 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             else wait_vmcnt_tied1(0, r0);
             write_row(j, 0, r0, r1);
         }
-    }
-    // SPF (software-pipelined fragments, XT == 0): the MFMA operands of step t+1 are read from LDS DURING step t
-    // (each X fragment is refilled as soon as its last MFMA has issued; the W fragments, live until the last MFMA,
-    // are refilled at the end of the step and fly during the barrier wait), so after a barrier the matrix pipe
-    // starts at once instead of waiting for 12 ds_read_b128.  That needs W(t+1) landed at the barrier of step t.
-    constexpr bool SPF = XT == 0;
-    // W(t + LEAD) is issued during step t into the stage of W(t-1), whose fragments were read during step t-2: TWO
-    // barriers lie between a stage's last ds_read and the DMA that overwrites it.  (With one barrier -- LEAD = NW --
-    // a ds_read issued before the barrier but still queued in the LDS pipe lost against the returning DMA about once
-    // per 10^5 tiles at two workgroups per CU: s_barrier does not wait for lgkmcnt.)
-    constexpr int LEAD = NW - 1;
-    constexpr int WOUT = SPF ? LEAD - 2 : NW - 2;  // W tiles issued after the one a barrier needs
 #pragma unroll
-    for (int t = 0; t < LEAD; ++t)
-        if (t < nk) issue_w(t, t % 9);
+        for (int t = 0; t < LEAD; ++t)
+            if (t < nk) issue_w(t, t % 9);
+    }
 
     // SPF operands.  K-steps run dx-major (step p of a chunk: dx = p / 3, dy = p % 3; the weights are packed in that
     // order), so the TP+2 halo rows a wave needs for one dx serve all three dy taps from REGISTERS: xr[r] = halo row r
@@ -350,7 +364,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 else { for (int r = tap - (NW - 1); r <= tap - 1; ++r) if (r >= 0 && r < NXW) n += LX; }
                 wait_vmcnt(n);
             } else {
-                int ahead = nk - 1 - (SPF ? t + 1 : t);
+                int ahead = 8 - tap - (SPF ? 1 : 0);       // nk - 1 - t (- 1): the last chunk ends the K-steps (nk = 9 * nchunk)
                 if (ahead > WOUT) ahead = WOUT;
                 if (ahead < 0) ahead = 0;
                 wait_vmcnt(ahead * wpw);
@@ -360,12 +374,12 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             __builtin_amdgcn_s_barrier();        // all waves' pieces of the tile (and X(chunk)) are in LDS;
             asm volatile("" ::: "memory");       // everyone is done reading the stage that is refilled next
             if constexpr (!SPF) {
-                if (!LAST || t + LEAD < nk) issue_w(t + LEAD, (tap + LEAD) % 9);
+                if (!LAST || tap + LEAD < 9) issue_w(t + LEAD, (tap + LEAD) % 9);
             }
 
             if constexpr (SPF && !DYR) {
                 // MFMAs of step t on registers filled during step t-1; meanwhile fetch step t+1's fragments
-                const bool has_next = !LAST || t + 1 < nk;
+                const bool has_next = !LAST || tap < 8;
                 const int tap_n = (tap + 1) % 9;
                 const int dy_n = tap_n / 3, dx_n = tap_n % 3;            // ky-major walk (KYMAJOR)
                 const char* xs_n = (tap == 8) ? xbase + ((chunk + 1) & 1) * XBUF : xs;
@@ -381,7 +395,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                         xr[j] = *(const bf16x8*)(xs_n + xaddr(rel & 7) + rel * HB);     // its last reader has issued
                     }
                     if (j == TP / 2 - 1) {
-                        if (!LAST || t + LEAD < nk) issue_w(t + LEAD, (tap + LEAD) % 9);
+                        if (!LAST || tap + LEAD < 9) issue_w(t + LEAD, (tap + LEAD) % 9);
                         if constexpr (!LAST) { if (tap == 0) issue_x_dma(chunk + 1); }
                     }
                 }
@@ -395,7 +409,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             if constexpr (SPF) {
                 // MFMAs of step t on registers filled earlier; meanwhile fetch the next group's halo rows / next step's W
                 const int dx = tap / 3, dy = tap % 3;
-                const bool has_next = !LAST || t + 1 < nk;                 // a next K-step exists (W fragments)
+                const bool has_next = !LAST || tap < 8;                 // a next K-step exists (W fragments)
                 const bool next_group = !LAST || dx < 2;                   // a next dx group exists (X fragments)
                 const int dx_n = (dx + 1) % 3;
                 const char* xs_n = (dx == 2) ? xbase + ((chunk + 1) & 1) * XBUF : xs;
@@ -421,7 +435,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                         if (dy == 2) refill(j + 2);
                     }
                     if (j == TP / 2 - 1) {
-                        if (!LAST || t + LEAD < nk) issue_w(t + LEAD, (tap + LEAD) % 9);
+                        if (!LAST || tap + LEAD < 9) issue_w(t + LEAD, (tap + LEAD) % 9);
                         if constexpr (!LAST) { if (tap == 0) issue_x_dma(chunk + 1); }
                     }
                 }
@@ -609,7 +623,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
         __syncthreads();                                   // every wave is done with the staging LDS
         STAMP(10);
         const int G = a.Cout / a.gn_cpg;
-        float* out = a.gn_partial + (((long long)b * (tiles_x * tiles_y) + tile) * G + c0 / a.gn_cpg) * 3;
+        float* out = a.gn_partial + (((long long)b * a.ptiles + tile) * G + c0 / a.gn_cpg) * 3;
         vt_gn_epilogue_partials_il<TC, TP>(acc, valid, a.gn_cpg, wp, WP, wc * 64, BC, (float*)smem, out);
     }
 #ifdef HALO_STAMP
@@ -639,7 +653,13 @@ hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
     const long long tiles = (long long)((a.W + TW - 1) / TW) * ((a.H + ROWS - 1) / ROWS);
     const long long nblk = tiles * (a.Cout / BC) * a.batch;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NWV), smem, s, a);
+    Conv3x3Args k = a;
+    k.tiles_x = (a.W + TW - 1) / TW; k.ctiles = a.Cout / BC; k.per_img = (int)(tiles * k.ctiles); k.ptiles = (int)tiles;
+    auto magic = [&](long long d) -> unsigned long long {           // n / d = (n * m) >> 40 for every n < nblk, when n * d < 2^40
+        return (nblk * d < (1LL << 40) && nblk < (1LL << 23)) ? ((1ULL << 40) / (unsigned long long)d + 1ULL) : 0ULL;
+    };
+    k.m_per_img = magic(k.per_img); k.m_ctiles = magic(k.ctiles); k.m_tiles_x = magic(k.tiles_x);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NWV), smem, s, k);
     return hipGetLastError();
 }
 

@@ -46,10 +46,11 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s);
 // which tile configuration the dispatcher picks for these args: 0 = 128x32, 1 = 256x128, 2 = 256x256
 int vt_conv_gemm_config(const ConvGemmArgs& a);
 const char* vt_conv_gemm_config_name(int cfg);
-constexpr int VT_NUM_MFMA_CONFIGS = 11;  // 0..2 conv_gemm tiles, 3..8 conv3x3_halo <tile, XT>, 9 conv_gemm two-workgroups-per-CU tile, 10 attn_qk
+// profile slots: 0..2 conv_gemm tiles, 3..8 conv3x3_halo variants, 9 conv_gemm two-workgroups-per-CU tile, 10 attn_qk, 11 fp8 halo conv
 constexpr int VT_PROF_ATTN_QK = 10;
-constexpr int VT_PROF_GN_APPLY = 11;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
-constexpr int VT_NUM_PROF_SLOTS = 12;
+constexpr int VT_PROF_HALO_FP8 = 11;
+constexpr int VT_PROF_GN_APPLY = 12;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 13;
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
@@ -90,6 +91,9 @@ struct Conv3x3Args {
     const bf16_t* scW;      // packed [scCin/32][Cout][32] bf16, rows in the interleaved cout order
     int scCin;
     int occ2;               // two-workgroups-per-CU tile mode 0..3 (vt_set_flag 3; see conv3x3_halo.hip)
+    // filled by the launcher: tile-grid constants of the chosen variant and their division multipliers (0 = divide)
+    int tiles_x, ctiles, per_img, ptiles;
+    unsigned long long m_per_img, m_ctiles, m_tiles_x;
 };
 // GroupNorm partials per image the epilogue of this (Cout, input mode xt 0..2, occ2 mode, fused shortcut) launch writes
 int vt_conv3x3_halo_tiles(int H, int W, int Cout, int xt, int occ2, int has_sc);
@@ -100,6 +104,25 @@ bool vt_conv3x3_halo_supported(int Cin, int Cout);
 int vt_conv3x3_halo_config(const Conv3x3Args& a);
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s);
 hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w_ohwi, bf16_t* wp, int Cin, int Cout, hipStream_t s);
+
+// 3x3 stride-1 pad-1 conv on fp8 (OCP e4m3) operands (conv3x3_halo_fp8.hip): out = acc * mult[cout] + bias[cout] (+ residual)
+struct Conv3x3Fp8Args {
+    const unsigned char* X;   // NHWC e4m3 [batch][H][W][Cin]: act_scale * activation
+    const unsigned char* Wp;  // packed [Cin/64][9 (kx-major)][Cout][64] e4m3, cout rows permuted (vt_halo_fp8_row_of_cout)
+    const float* mult;        // [Cout]: weight scale / act_scale
+    const float* bias;        // [Cout] or null
+    const float* res; const f16_t* res_f16;               // optional residual (at most one)
+    float* out_f32; bf16_t* out_bf16; f16_t* out_f16;     // at least one
+    const void* zeros;
+    float* gn_partial; int gn_cpg;                         // optional [batch][tiles][Cout/gn_cpg][3]
+    int batch, H, W, Cin, Cout;
+    int tiles_x, ctiles, per_img, ptiles;                  // filled by the launcher
+    unsigned long long m_per_img, m_ctiles, m_tiles_x;
+};
+bool vt_conv3x3_halo_fp8_supported(int Cin, int Cout);
+int vt_conv3x3_halo_fp8_tiles(int H, int W);              // GroupNorm partials per image its epilogue writes
+int vt_halo_fp8_row_of_cout(int cout_local /*0..31*/);
+hipError_t vt_launch_conv3x3_halo_fp8(const Conv3x3Fp8Args& a, hipStream_t s);
 
 // conv_in: fp32 NCHW image -> NHWC 128-channel fp32 (+ optional bf16) rows, direct fp32 conv 3x3 p1.
 // gn_partial (optional): (n, mean, M2) triples of the output, [B][parts][Cout/gn_cpg][3]; *gn_parts receives `parts`.
@@ -121,9 +144,9 @@ hipError_t vt_launch_gn_finalize(const float* partial /*[B][nparts][groups][3]*/
                                  float eps, const float* gamma, const float* beta, float* scale_shift /*[B][C][2]*/,
                                  hipStream_t s, int* status = nullptr /* device word: bit 0 raised on non-finite statistics */);
 int vt_gn_max_chunks(int HW, int C);
-// y = act(x*scale + shift) -> bf16 rows
-hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shift, bf16_t* y, int B, int HW,
-                              int C, int silu, hipStream_t s);
+// y = act(x*scale + shift) -> bf16 rows, or (out_fp8_scale > 0) e4m3 rows of out_fp8_scale * y, saturated at +-448
+hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shift, void* y, int B, int HW,
+                              int C, int silu, hipStream_t s, float out_fp8_scale = 0.f);
 
 hipError_t vt_launch_preprocess_u8(const unsigned char* in_hwc, float* out_nchw, int B, int H, int W, hipStream_t s);
 // Pillow's two-pass 8-bit resample; tab_*: [n_out][2 + ksize] int32 (first, count, 22-bit coefficients) on the device;
