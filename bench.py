@@ -124,11 +124,12 @@ def cpu_baseline(x0, tags, flops_target, budget_s=85.0):
                  "rows": rows, "total_seconds": round(time.perf_counter() - t_start, 1)}
 
 
-def pmc_traffic(kernel, batch, height, width):
+def pmc_traffic(kernel, batch, height, width, fp8=False):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (tools/profile_round.sh: separate
     FETCH_SIZE and WRITE_SIZE passes; both in KB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).
     Only valid for the workload the counters were collected on (batch 16 x 1024^2); None otherwise."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic_b16_1024.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02",
+                        f"pmc_traffic_b16_1024_{'fp8' if fp8 else 'bf16'}.json")
     if (batch, height, width) != (16, 1024, 1024) or not os.path.exists(path):
         return None, None
     want = kernel.replace(" ", "")
@@ -155,11 +156,19 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # rehearsal on a one-GPU box (never used by the driver): VT_BENCH_REHEARSAL=1 puts every rank on GPU 0 and uses gloo for
+    # the collectives, so the N > 1 control flow (rank-distinct inputs, all-gather, max-over-ranks timing) runs without RCCL
+    rehearsal = os.environ.get("VT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     from vae_tagger_amd import sharding, synth
     from vae_tagger_amd.diffusers_vae_loader import (DiffusersVAEWrapper, get_diffusers_vae_config,
@@ -296,7 +305,7 @@ def main():
         dom_peak = MFMA_FP8_DENSE_PEAK_TFLOPS if b"fp8" in names[dom] else MFMA_BF16_DENSE_PEAK_TFLOPS
         gemm_ms = sum(tot_ms[i] for i in range(nm))
         gn_gbs = tot_fl[nm] / (tot_ms[nm] * 1e-3) / 1e9 if tot_ms[nm] > 0 else 0.0
-        traffic, traffic_src = (None, None) if (a.bucketed or a.encode_only) else pmc_traffic(names[dom].decode(), B, a.height, a.width)
+        traffic, traffic_src = (None, None) if (a.bucketed or a.encode_only) else pmc_traffic(names[dom].decode(), B, a.height, a.width, a.fp8)
         res = {
             "metric": ("images/sec encode+tag, bucketed 512..1024 bf16" if a.bucketed else
                        "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16").replace(
