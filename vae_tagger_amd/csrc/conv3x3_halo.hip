@@ -569,6 +569,27 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     const long long ob = (long long)b * HWp * a.Cout;
     const int x = tx0 + fr;
     const int cw = c0 + wc * 64 + 16 * fq;               // first of this lane's 16 couts
+    // fp16 residual: fetched with ONE LDS-DMA burst per wave (its own TPW rows x 16 px x 64 couts, into the staging buffers the
+    // main loop no longer needs) instead of TPW dependent global-load round trips inside the store loop (conv2 layers: -3 % on
+    // the fp8 kernel, where the same change was measured first).  Piece p of a wave = pixels 8 p .. 8 p + 7 of its region x
+    // 128 B; lane l -> pixel (l >> 3), physical 16-B chunk (l & 7), logical chunk = physical ^ (pixel & 7).
+    constexpr int RPCS = TPW * 2;                        // 1-KB pieces per wave
+    constexpr bool RES_DMA = NWV * RPCS * 1024 <= 2 * XBUF + NW * WBUF;
+    char* const rbuf = smem + wave * (RPCS * 1024);
+    if (RES_DMA && a.res_f16) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                 // every wave has read its last fragments: the buffers are free
+#pragma unroll 4
+        for (int pc = 0; pc < RPCS; ++pc) {
+            const int pp = pc * 8 + (lane >> 3);
+            const int yy = ty0 + wp * TPW + (pp >> 4), xx = tx0 + (pp & 15);
+            const int lc = (lane & 7) ^ (pp & 7);
+            const void* src = (yy < a.H && xx < a.W)
+                ? (const void*)(a.res_f16 + ob + ((long long)yy * a.W + xx) * a.Cout + c0 + wc * 64 + lc * 8) : a.zeros;
+            __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(rbuf + pc * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's residual tile is in LDS (only this wave reads it)
+    }
     unsigned valid = 0;
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
@@ -585,10 +606,12 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
         }
         if (a.res_f16) {
             // fp16 residual stream: the lane's 16 couts are 32 contiguous bytes
+            const int pp = j * 16 + fr;
 #pragma unroll
             for (int i = 0; i < TC; i += 2) {
                 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-                const f16x8 rh = *(const f16x8*)(a.res_f16 + o + 4 * i);
+                const f16x8 rh = RES_DMA ? *(const f16x8*)(rbuf + pp * 128 + (((2 * fq + (i >> 1)) ^ (pp & 7)) << 4))
+                                         : *(const f16x8*)(a.res_f16 + o + 4 * i);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { acc[i][j][r] += (float)rh[r]; acc[i + 1][j][r] += (float)rh[4 + r]; }
             }

@@ -220,6 +220,23 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
     const int HWp = a.H * a.W;
     const long long ob = (long long)b * HWp * a.Cout;
     const int x = tx0 + li;
+    // fp16 residual: fetched with ONE LDS-DMA burst per wave (its own 4 rows x 32 px x 64 couts = 16 KB, into the staging
+    // buffers the main loop no longer needs) instead of eight dependent global-load round trips inside the store loop.
+    // Piece p of a wave = pixels 8 p .. 8 p + 7 of its region x 128 B; lane l -> pixel (l >> 3), physical 16-B chunk (l & 7),
+    // logical chunk = physical ^ (pixel & 7) (rows 128 B apart: 2-way instead of 8-way bank conflicts on the reads).
+    char* const rbuf = smem + wave * 16384;
+    if (a.res_f16) {
+        __syncthreads();                                 // every wave has read its last fragments: the buffers are free
+#pragma unroll 4
+        for (int pc = 0; pc < 16; ++pc) {
+            const int pp = pc * 8 + (lane >> 3);
+            const int yy = ty0 + wp * TP + (pp >> 5), xx = tx0 + (pp & 31);
+            const int lc = (lane & 7) ^ (pp & 7);
+            const void* src = (yy < a.H && xx < a.W)
+                ? (const void*)(a.res_f16 + ob + ((long long)yy * a.W + xx) * a.Cout + c0 + wc * 64 + lc * 8) : a.zeros;
+            __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(rbuf + pc * 1024), 16, 0, 0);
+        }
+    }
     unsigned valid = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
             mul[i] = *(const f32x4*)(a.mult + cw + 4 * i);
             bia[i] = a.bias ? *(const f32x4*)(a.bias + cw + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (h == 0 && a.res_f16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's residual tile is in LDS
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int y = ty0 + wp * TP + j;
@@ -248,9 +266,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
                 }
             }
             if (a.res_f16) {
+                const int pp = j * 32 + li;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const f16x8 rh = *(const f16x8*)(a.res_f16 + o + 8 * i);
+                    const f16x8 rh = *(const f16x8*)(rbuf + pp * 128 + (((4 * h + 2 * g + i) ^ (pp & 7)) << 4));
 #pragma unroll
                     for (int q = 0; q < 8; ++q) acc[h][j][8 * i + q] += (float)rh[q];
                 }

@@ -211,7 +211,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
             o1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], o1, false);
             o1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], o1, true);
             typedef int i32x2 __attribute__((ext_vector_type(2)));
+#ifdef GN8_PLAIN_STORE
+            *(i32x2*)((unsigned char*)yv + base + (long long)p * C) = i32x2{o0, o1};
+#else
             __builtin_nontemporal_store(i32x2{o0, o1}, (i32x2*)((unsigned char*)yv + base + (long long)p * C));
+#endif
         } else {
             bf16x8 o;
 #pragma unroll
