@@ -298,7 +298,7 @@ def test_fp16_overflow_trips_the_status_word_and_fp32_storage_matches_oracle():
     assert (lat32.cpu() - ref).abs().max().item() <= TOL_LATENT_BF16
 
 
-@pytest.mark.parametrize("res", [256, 512])
+@pytest.mark.parametrize("res", [256, 512, 1024])
 def test_config4_fp8_operands_keep_the_logits_within_tolerance(vae, res):
     """BASELINE.json configs[4] (opt-in, vt_set_flag(ctx, 11, 1)): the 20 stride-1 3x3 resnet convs on fp8 e4m3 operands.
     north_star's fp8 target line constrains the LOGITS (within 1e-2 of the CPU reference); the latents are documented to move by
@@ -473,3 +473,26 @@ def test_device_resize_is_bit_exact_with_pillow(vae):
     assert np.array_equal(pipe.resize_u8(a, 192, 256, pipe.FILTER_LANCZOS, box).cpu().numpy(), want)
     for kw, ref_t in (({"resolution": 128}, get_image_transform(128)), ({"bucket": (192, 256)}, get_image_transform(0, True, (192, 256)))):
         assert torch.equal(pipe.load_image(img, **kw).cpu(), ref_t(img))
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal(tmp_path):
+    """The N > 1 control flow of bench.py with the HIP path under it: two ranks, both on GPU 0, gloo for the collectives
+    (VT_BENCH_REHEARSAL=1; RCCL needs one GPU per rank, which this box does not have).  Rank-distinct inputs, one all-gather of
+    logits per step, max-over-ranks timing, ONE JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VT_BENCH_REHEARSAL="1", PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29600 + os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--height", "256", "--width", "256", "--tags", "1000"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
+    assert res["value"] > 0 and res["scaling"] == "weak" and "cpu_baseline" not in res
