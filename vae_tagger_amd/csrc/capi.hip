@@ -31,6 +31,7 @@ struct ResnetW {
     NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0;
     // conv_shortcut fused into conv2's launch (Conv3x3Args::scW): [cin/32][cout][32] bf16, interleaved cout rows; bias c2 + sc
     const bf16_t* sc_wp = nullptr; const float* b_c2sc = nullptr;
+    const bf16_t* sc_wp8 = nullptr;      // the same for the fp8 conv2: rows in its cout order, values divided by conv2's mult[cout]
 };
 struct AttnW { NormW gn; const bf16_t *wqk = nullptr, *wv = nullptr, *wo = nullptr; const float *bqk = nullptr, *bv = nullptr, *bo = nullptr; int c = 0; };
 struct StageW { std::vector<ResnetW> res; bool has_down = false; ConvW down; };
@@ -258,6 +259,21 @@ int get_resnet(vt_context* c, const std::string& p, int cin, int cout, ResnetW* 
         r->sc_wp = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
         r->b_c2sc = (const float*)c->upload(bb.data(), bb.size() * 4);
         if (!r->sc_wp || !r->b_c2sc) return c->fail(VT_ERR_HIP, "upload failed for %s.conv_shortcut", p.c_str());
+        if (r->c2.wp8) {
+            // fp8 conv2: its epilogue multiplies the accumulator by mult[cout] = scale / 8, so the shortcut rows carry 1 / mult
+            const HostTensor* w2 = c->find(p + ".conv2.weight");
+            std::vector<uint16_t> h8((size_t)cin * cout);
+            for (int o = 0; o < cout; ++o) {
+                float amax = 0.f;
+                for (size_t i = 0; i < (size_t)cout * 9; ++i) amax = fmaxf(amax, fabsf(w2->v[(size_t)o * cout * 9 + i]));
+                const float mult = (amax > 0.f ? amax / 448.f : 1.f) / FP8_ACT_SCALE;
+                const int row = (o & ~31) + vt_halo_fp8_row_of_cout(o & 31);
+                for (int i = 0; i < cin; ++i)
+                    h8[((size_t)(i >> 5) * cout + row) * 32 + (i & 31)] = f2bf(w->v[(size_t)o * cin + i] / mult);
+            }
+            r->sc_wp8 = (const bf16_t*)c->upload(h8.data(), h8.size() * 2);
+            if (!r->sc_wp8) return c->fail(VT_ERR_HIP, "upload failed for %s.conv_shortcut", p.c_str());
+        }
     }
     return VT_OK;
 }
@@ -339,7 +355,7 @@ hipError_t launch_halo_fp8(vt_context* c, const Conv3x3Fp8Args& a, hipStream_t s
     vt_context::ProfRec r;
     r.e0 = c->next_event(); r.e1 = c->next_event();
     if (!r.e0 || !r.e1) return hipErrorOutOfMemory;
-    r.flops = 2.0 * a.batch * (double)a.H * a.W * a.Cout * 9.0 * a.Cin;
+    r.flops = 2.0 * a.batch * (double)a.H * a.W * a.Cout * (9.0 * a.Cin + (a.scX ? a.scCin : 0));
     r.cfg = VT_PROF_HALO_FP8;
     hipError_t e = hipEventRecord(r.e0, s);
     if (e != hipSuccess) return e;
@@ -387,7 +403,7 @@ int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int
 // fused into the halo staging (only valid when norm_conv_fusable()).
 // `res` / `oh` are the residual-stream tensors (input to add, output to write): fp32 when rdt == 1, fp16 when rdt == 2.
 // `sc`: a 1x1 conv of sc->x fused into the halo launch (resnet conv_shortcut); then `res` must be null.
-struct ScFuse { const bf16_t* x; const bf16_t* wp; const float* bias; int cin; };
+struct ScFuse { const bf16_t* x; const bf16_t* wp; const float* bias; int cin; const bf16_t* wp8; };
 int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int Win, int stride, int pad, int Hout,
              int Wout, const void* res, void* oh, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32,
              const float* xnorm_f32 = nullptr, const float* ss = nullptr, int rdt = 1, const ScFuse* sc = nullptr,
@@ -400,11 +416,12 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     const bool fuse = gn && c->fuse_gn_stats && (cpg == 4 || cpg == 8 || cpg == 16);
     if (gn) gn->parts = 0;
     if (x_fp8) {
-        if (!w.wp8 || w.k != 3 || stride != 1 || pad != 1 || ss || sc) return c->fail(VT_ERR_STATE, "internal: fp8 operands requested for a conv the fp8 kernel cannot run");
+        if (!w.wp8 || w.k != 3 || stride != 1 || pad != 1 || ss || (sc && !sc->wp8)) return c->fail(VT_ERR_STATE, "internal: fp8 operands requested for a conv the fp8 kernel cannot run");
         Conv3x3Fp8Args h{};
         h.X = (const unsigned char*)x; h.Wp = w.wp8; h.mult = w.mult8; h.bias = w.b; h.res = res32; h.res_f16 = res16;
         h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
+        if (sc) { h.scX = sc->x; h.scW = sc->wp8; h.scCin = sc->cin; h.bias = sc->bias; }
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_fp8_tiles(Hin, Win); }
         HIPCK(c, launch_halo_fp8(c, h, s), "conv3x3_halo_fp8");
         return VT_OK;
@@ -446,7 +463,7 @@ bool norm_conv_fusable(const vt_context* c, const ConvW& w, int cin) {
 int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, int xdt, int B, int H, int W,
                   int groups, bf16_t* act, const void* res, void* oh, bf16_t* o16, GnState& gn, bool want_stats,
                   hipStream_t s, int rdt, const ScFuse* sc = nullptr) {
-    const bool f8 = c->fp8 && w.wp8 && w.k == 3 && !sc;      // fp8 operands: the GroupNorm-apply pass writes e4m3, the conv reads it
+    const bool f8 = c->fp8 && w.wp8 && w.k == 3 && (!sc || sc->wp8);      // fp8 operands: the GroupNorm-apply pass writes e4m3, the conv reads it
     if (f8 || xdt == 2 || !norm_conv_fusable(c, w, n.c)) {   // (the fused staging reads fp32 or bf16 only)
         int r = run_gn(c, x, xdt, B, H * W, n, groups, 1, act, gn, s, f8);
         if (r) return r;
@@ -881,14 +898,15 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
         gn.parts = fuse0 ? parts : 0;
     }
 
-    // (the fp8 kernel has no fused-shortcut K-steps: with fp8 operands the shortcut is its own GEMM launch)
-    auto fuse_sc = [&](const ResnetW& rw) { return c->fuse_shortcut && rw.sc_wp && c->use_halo_conv && rw.c2.wp && !c->fuse_gn_apply && !(c->fp8 && rw.c2.wp8); };
+    auto fuse_sc = [&](const ResnetW& rw) {
+        return c->fuse_shortcut && rw.sc_wp && c->use_halo_conv && rw.c2.wp && !c->fuse_gn_apply && (!(c->fp8 && rw.c2.wp8) || rw.sc_wp8);
+    };
     // one ResnetBlock2D: h <- conv2(silu(gn(conv1(silu(gn(h)))))) + shortcut(h)
     auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out) -> int {
         const int nxt = (cur + 1) % 3, scb = (cur + 2) % 3;
         const void* res = f32[cur];
         int rr;
-        ScFuse scf{h16_for_shortcut, rw.sc_wp, rw.b_c2sc, rw.cin};
+        ScFuse scf{h16_for_shortcut, rw.sc_wp, rw.b_c2sc, rw.cin, rw.sc_wp8};
         const ScFuse* sc = nullptr;
         if (rw.has_sc) {
             if (fuse_sc(rw)) {

@@ -208,6 +208,51 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
     };
     for (int chunk = 0; chunk + 1 < nchunk; ++chunk) do_chunk(chunk, std::false_type{});
     do_chunk(nchunk - 1, std::true_type{});
+    if (a.scX) {
+        // ---- fused 1x1 shortcut (a resnet block's conv_shortcut): acc += scW . scX at the tile's own pixels, as scCin / 32 plain
+        // K-steps of bf16 32x32x16 MFMAs on the SAME accumulators (the fp8 and bf16 32x32 forms share the accumulator layout).
+        // scW is pre-divided by mult[cout] on the host, so the epilogue's acc * mult + bias scales it back.
+        const bf16_t* Xs = a.scX + (long long)b * a.H * a.W * a.scCin;
+        const int scn = a.scCin >> 5;
+#pragma nounroll
+        for (int c = 0; c < scn; ++c) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                        // the staging buffers are free
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                        // the tile's 8 x 32 pixels, 16 per piece, 4 pieces per wave
+                const int pp = (j * NWV + wave) * 16 + drow;
+                const int iy = ty0 + (pp >> 5), ix = tx0 + (pp & 31);
+                const void* src = (iy < a.H && ix < a.W) ? (const void*)(Xs + ((long long)(iy * a.W + ix) * a.scCin + c * 32 + dchunk * 8)) : a.zeros;
+                __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(xbase + (j * NWV + wave) * 1024), 16, 0, 0);
+            }
+            const bf16_t* wt = a.scW + ((long long)c * a.Cout + c0 + wave * 16 + drow) * 32 + dchunk * 8;
+#pragma unroll
+            for (int j = 0; j < WPW; ++j)
+                __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(wt + j * NWV * 16 * 32), VT_LDS_PTR(wbase + (j * NWV + wave) * 1024), 16, 0, 0);
+            wait_vmcnt(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {                     // k = 16 ks + 8 g .. + 7: logical 16-B chunk 2 ks + g
+                bf16x8 wf[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = wrow0 + 32 * h;
+                    wf[h] = *(const bf16x8*)(wbase + row * HB + (((2 * ks + g) ^ swz(row)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    const int row = (wp * TP + j) * 32 + li;
+                    const bf16x8 xf = *(const bf16x8*)(xbase + row * HB + (((2 * ks + g) ^ swz(row)) << 4));
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        acc[h][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[h], xf, acc[h][j], 0, 0, 0);
+                }
+            }
+        }
+    }
     // pin the accumulators here: left alone, the compiler sinks each chain's last MFMAs into the epilogue's conditional
     // blocks (behind the first stores), keeps the operand fragments alive for them and spills ~100 registers
 #pragma unroll
@@ -373,6 +418,8 @@ hipError_t vt_launch_conv3x3_halo_fp8(const Conv3x3Fp8Args& a, hipStream_t s) {
     if (a.gn_partial && a.gn_cpg != 4 && a.gn_cpg != 8 && a.gn_cpg != 16) return hipErrorInvalidValue;
     if ((long long)a.H * a.W * a.Cin >= (1LL << 31)) return hipErrorInvalidValue;        // 32-bit per-image offsets
     if ((long long)(a.Cin / 64) * 9 * a.Cout * 64 >= (1LL << 31)) return hipErrorInvalidValue;
+    if ((a.scX != nullptr) != (a.scW != nullptr)) return hipErrorInvalidValue;
+    if (a.scX && (a.scCin <= 0 || (a.scCin % 32) || a.res || a.res_f16 || (long long)a.H * a.W * a.scCin >= (1LL << 31))) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> attr_done{0};
     hipError_t ea = vt_once_per_device(attr_done, [&] { return hipFuncSetAttribute((const void*)conv3x3_halo_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); });
     if (ea != hipSuccess) return ea;

@@ -116,6 +116,9 @@ struct Conv3x3Fp8Args {
     const void* zeros;
     float* gn_partial; int gn_cpg;                         // optional [batch][tiles][Cout/gn_cpg][3]
     int batch, H, W, Cin, Cout;
+    // optional fused 1x1 conv (conv_shortcut) on bf16 operands: out += scW . scX; then no residual.  scX NHWC bf16
+    // [batch][H][W][scCin]; scW [scCin/32][Cout rows in the fp8 kernel's permuted order][32] bf16, pre-divided by mult[cout]
+    const bf16_t* scX; const bf16_t* scW; int scCin;
     int tiles_x, ctiles, per_img, ptiles;                  // filled by the launcher
     unsigned long long m_per_img, m_ctiles, m_tiles_x;
 };
