@@ -135,6 +135,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         registers, keys streamed through LDS, row sums in registers); 0 = the generic GEMM with the exp epilogue.
  * flag 10: 1 (default) = P.V reads the probabilities (4+ GB per launch, read once) with the streaming (nt) cache policy so they
  *         do not displace the rest of the working set from L2 / Infinity Cache; 0 = default policy.
+ * flag 12: 1 (default) = with flag 9, Q.K^T stores the probabilities in the MFMA fragment order it holds them in and P.V runs on its
+ *         own kernel that loads them straight into registers (only v^T passes through LDS); 0 = row-major P + the generic GEMM.
  * flag 11: 1 = BASELINE.json configs[4]: the 20 stride-1 3x3 resnet convolutions run on fp8 (OCP e4m3) operands on the fp8 MFMA
  *         (v_mfma_scale_f32_32x32x64_f8f6f4, 2x the bf16 rate): weights e4m3 with per-output-channel scales, activations e4m3(8 x)
  *         written by the GroupNorm-apply pass; fp32 accumulate, everything else unchanged.  OPT-IN, for tagging only: latents move

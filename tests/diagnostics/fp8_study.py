@@ -71,6 +71,39 @@ def _conv(x, sd, name, q, stride=1, padding=1):
 
 encoder_ref._conv = _conv
 
+ATTN_FP8 = {"p": False, "v": False, "qk": False}
+_orig_attention = encoder_ref._attention
+
+
+def _attention(h, sd, p, q):
+    """encoder_ref._attention with optional e4m3 P (un-normalised numerators exp(s - rowmax), scaled by 64), V and q / k."""
+    import math
+    if not any(ATTN_FP8.values()):
+        return _orig_attention(h, sd, p, q)
+    b, c, hh, ww = h.shape
+    x = F.group_norm(h, encoder_ref.GN_GROUPS, sd[p + ".group_norm.weight"], sd[p + ".group_norm.bias"], encoder_ref.GN_EPS)
+    x = q(x).reshape(b, c, hh * ww).transpose(1, 2)
+    qq = q(F.linear(x, q(sd[p + ".to_q.weight"]), sd[p + ".to_q.bias"]))
+    kk = q(F.linear(x, q(sd[p + ".to_k.weight"]), sd[p + ".to_k.bias"]))
+    vv = q(F.linear(x, q(sd[p + ".to_v.weight"]), sd[p + ".to_v.bias"]))
+    if ATTN_FP8["qk"]:
+        qq, kk = q_act(qq, "tensor"), q_act(kk, "tensor")
+    scores = torch.matmul(qq, kk.transpose(1, 2)) * (1.0 / math.sqrt(c))
+    num = torch.exp(scores - scores.amax(dim=-1, keepdim=True))
+    den = num.sum(dim=-1, keepdim=True)                       # the fp32 numerators' sum, as the Q.K^T epilogue takes it
+    if ATTN_FP8["p"]:
+        num = e4m3(num * 64.0) / 64.0
+    else:
+        num = q(num)
+    if ATTN_FP8["v"]:
+        vv = q_act(vv, "tensor")
+    o = q(torch.matmul(num, vv) / den)
+    o = F.linear(o, q(sd[p + ".to_out.0.weight"]), sd[p + ".to_out.0.bias"])
+    return o.transpose(1, 2).reshape(b, c, hh, ww) + h
+
+
+encoder_ref._attention = _attention
+
 
 def conv_layers(sd):
     """3x3 convs of the encoder except conv_in / conv_out, with (cin, cout)."""
@@ -122,6 +155,11 @@ def main():
     report("fp8 e4m3, Cin >= 256 layers only, act scale = tensor", Policy(big, "tensor"))
     report("fp8 e4m3, Cin >= 256 layers only, act scale = mx", Policy(big, "mx"))
     report("fp8 e4m3, stride-1 resnet convs only, act scale = tensor", Policy(s1, "tensor"))
+    for label, cfg in (("+ attention P in e4m3", dict(p=True)), ("+ attention P and V in e4m3", dict(p=True, v=True)),
+                       ("+ attention P, V, q, k in e4m3", dict(p=True, v=True, qk=True))):
+        ATTN_FP8.update(dict(p=False, v=False, qk=False)); ATTN_FP8.update(cfg)
+        report("fp8 stride-1 resnet convs " + label, Policy(s1, "tensor"))
+    ATTN_FP8.update(dict(p=False, v=False, qk=False))
     if per_layer:
         print("per-layer sensitivity (ONE layer on fp8 operands, act scale = tensor):", flush=True)
         rows = []

@@ -393,8 +393,9 @@ def test_mid_attention_without_softmax_pass(gain, S):
     ws = torch.empty(ctx.lib.vt_op_attention_workspace_bytes(B, S, C), dtype=torch.uint8, device="cuda")
     xd, rd = x.cuda(), res.cuda()
     try:
-        for qk in (1, 0):                                           # dedicated Q.K^T kernel / generic GEMM with the exp epilogue
+        for qk, pv in ((1, 1), (1, 0), (0, 0)):                     # dedicated Q.K^T (+ fragment-order P.V) kernels / generic GEMMs
             ctx.call("vt_set_flag", 9, qk)
+            ctx.call("vt_set_flag", 12, pv)
             outs = []
             for mode in (0, 1, 2):
                 ctx.call("vt_set_flag", 7, mode)
@@ -409,6 +410,7 @@ def test_mid_attention_without_softmax_pass(gain, S):
     finally:
         ctx.call("vt_set_flag", 7, 0)
         ctx.call("vt_set_flag", 9, 1)
+        ctx.call("vt_set_flag", 12, 1)
 
 
 def test_evaluation_caller_matches_oracle(vae, tmp_path):

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     for (int j = 0; j < 2; ++j) {
         const int row = row0 + j * 16 + fr;
         rv[j] = MODE == 1 ? -__builtin_inff() : 0.f;
-        sh2[j] = (MODE == 2 && row < a.S) ? a.rowin[(long long)b * a.row_bs + row] * 1.44269504f : 0.f;
+        sh2[j] = (MODE >= 2 && row < a.S) ? a.rowin[(long long)b * a.row_bs + row] * 1.44269504f : 0.f;
     }
     const float alpha2 = a.alpha * 1.44269504f;
 
@@ -95,6 +95,22 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     const int sr = lane >> 2, sp = lane & 3;                   // after the permute: this lane stores row sr, piece sp
     const int perm_addr = (sp * 16 + sr) << 2;                 // ... which it takes from lane 16 sp + sr
     auto store_held = [&](int kt_prev) __attribute__((always_inline)) {
+        if constexpr (MODE == 3) {
+            // fragment order (attn_pv.hip): piece (j, h) of this lane as it stands -- 1 KB contiguous per store instruction,
+            // the wave's stream over the key tiles sequential in memory
+            if (row0 < a.S) {
+                bf16_t* dst = a.P + (long long)b * a.p_bs + (long long)(row0 >> 5) * vt_attn_pt_slab_stride(a.S) + (long long)kt_prev * 2048 + lane * 8;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+#ifdef PFRAG_PLAIN
+                    for (int h = 0; h < 2; ++h) *(bf16x8*)(dst + (j * 2 + h) * 512) = hold[j][h];
+#else
+                    for (int h = 0; h < 2; ++h) __builtin_nontemporal_store(hold[j][h], (bf16x8*)(dst + (j * 2 + h) * 512));
+#endif
+            }
+            return;
+        }
         const int key0 = kt_prev * KT + 8 * sp;                // half h: keys key0 + 32 h .. + 7
         const bool full = kt_prev * KT + KT <= a.S;
 #pragma unroll
@@ -129,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
                     }
                 }
         }
-        if (MODE == 2) {
+        if (MODE == 2) {  /* row-major P: lane permute */
             typedef int i32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -161,9 +177,9 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
         // the early ones after their MFMAs (beside the partner's) -- not all eight waves at once behind the barrier.
         if (late) {
             if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
-            if (kt > 0) { epilogue(kt - 1); if (MODE == 2) store_held(kt - 1); }
+            if (kt > 0) { epilogue(kt - 1); if (MODE >= 2) store_held(kt - 1); }
         } else {
-            if (MODE == 2 && kt > 0) store_held(kt - 1);       // (a whole interval before the next vmcnt(0))
+            if (MODE >= 2 && kt > 0) store_held(kt - 1);       // (a whole interval before the next vmcnt(0))
         }
         const char* ks_base = smem + (kt & 1) * KBUF;
 #pragma unroll
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     }
     if (nkt > 0) {
         if (late) epilogue(nkt - 1);
-        if (MODE == 2) store_held(nkt - 1);
+        if (MODE >= 2) store_held(nkt - 1);
     }
     // ---- the four fq lanes of a row hold its other keys
 #pragma unroll
@@ -206,7 +222,9 @@ bool vt_attn_qk_supported(int S, int C) { return C == D && S > 0; }
 hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s) {
     if (!a.q || !a.k || !a.rowout || !a.zeros || a.batch <= 0 || !vt_attn_qk_supported(a.S, a.C)) return hipErrorInvalidValue;
     if (a.mode != 1 && a.mode != 2) return hipErrorInvalidValue;
-    if (a.mode == 2 && (!a.P || !a.rowin || (a.ldp % 8) || a.ldp < a.S || (a.p_bs % 8))) return hipErrorInvalidValue;
+    if (a.mode == 2 && (!a.P || !a.rowin || (a.p_bs % 8))) return hipErrorInvalidValue;
+    if (a.mode == 2 && !a.p_frag && ((a.ldp % 8) || a.ldp < a.S)) return hipErrorInvalidValue;
+    if (a.mode == 2 && a.p_frag && a.p_bs < vt_attn_pt_elems(a.S)) return hipErrorInvalidValue;
     if ((a.ldq % 8) || (a.qk_bs % 8) || a.row_bs < a.S) return hipErrorInvalidValue;
     if ((long long)a.S * a.ldq >= (1LL << 31)) return hipErrorInvalidValue;
     const long long nblk = (long long)((a.S + QB - 1) / QB) * a.batch;
@@ -215,10 +233,12 @@ hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s) {
     hipError_t ea = vt_once_per_device(attr_done, [&] {
         hipError_t e = hipFuncSetAttribute((const void*)attn_qk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_qk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_qk_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF);
         return e;
     });
     if (ea != hipSuccess) return ea;
     if (a.mode == 1) hipLaunchKernelGGL(attn_qk_kernel<1>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
+    else if (a.p_frag) hipLaunchKernelGGL(attn_qk_kernel<3>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
     else hipLaunchKernelGGL(attn_qk_kernel<2>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
     return hipGetLastError();
 }

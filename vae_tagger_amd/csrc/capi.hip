@@ -128,6 +128,7 @@ struct vt_context {
     int fuse_shortcut = 1;          // vt_set_flag(ctx, 8, v): resnet conv_shortcut inside conv2's launch
     int pv_stream = 1;              // vt_set_flag(ctx, 10, v): P.V reads P (4+ GB, read once) with the streaming cache policy
     int attn_qk_kernel = 1;         // vt_set_flag(ctx, 9, v): dedicated Q.K^T kernel (attn_qk.hip) instead of the generic GEMM
+    int attn_pv_kernel = 1;         // vt_set_flag(ctx, 12, v): P.V on its own kernel, P in MFMA fragment order (attn_pv.hip)
     int fp8 = 0;                    // vt_set_flag(ctx, 11, v): stride-1 3x3 resnet convs on fp8 (e4m3) operands (BASELINE configs[4])
     int halo_occ2 = 3;              // vt_set_flag(ctx, 3, v): two-workgroups-per-CU tile mode of the halo conv
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
@@ -504,10 +505,15 @@ int attn_group(int B, int S) {
 }
 // (row, column slot) partials per row: every tile configuration gives a wave 64 columns (the 32-column one has one slot)
 size_t attn_slots_bound(int S) { return (size_t)(S + 7) / 8 * 8 / 64 + 4; }
+// elements of one image's probabilities: the [S][pitch] matrix or its fragment-ordered form (attn_pv.hip), whichever is larger
+size_t attn_p_elems(int S) {
+    const size_t rowmajor = (size_t)S * attn_pitch(S), frag = (size_t)vt_attn_pt_elems(S);
+    return rowmajor > frag ? rowmajor : frag;
+}
 size_t attn_scratch_bytes(int B, int S, int C) {
     const size_t ld = attn_pitch(S), G = (size_t)attn_group(B, S);
     return align_up((size_t)B * S * 2 * C * 2) + align_up((size_t)B * C * ld * 2) + align_up(G * S * ld * 2) +
-           align_up(G * S * ld * 2) + align_up((size_t)B * S * C * 2) + 5 * align_up((size_t)B * S * 4) +
+           align_up(G * attn_p_elems(S) * 2) + align_up((size_t)B * S * C * 2) + 5 * align_up((size_t)B * S * 4) +
            align_up(G * attn_slots_bound(S) * S * 4) + align_up((size_t)B * 4);
 }
 AttnScratch carve_attn(char* p, int B, int S, int C) {
@@ -517,7 +523,7 @@ AttnScratch carve_attn(char* p, int B, int S, int C) {
     a.qk = (bf16_t*)p; p += align_up((size_t)B * S * 2 * C * 2);
     a.vt = (bf16_t*)p; p += align_up((size_t)B * C * ld * 2);
     a.scores = (f16_t*)p; p += align_up(G * S * ld * 2);
-    a.probs = (bf16_t*)p; p += align_up(G * S * ld * 2);
+    a.probs = (bf16_t*)p; p += align_up(G * attn_p_elems(S) * 2);
     a.o = (bf16_t*)p; p += align_up((size_t)B * S * C * 2);
     a.qn = (float*)p; p += align_up((size_t)B * S * 4);
     a.kn = (float*)p; p += align_up((size_t)B * S * 4);
@@ -559,6 +565,7 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
     for (int b0 = 0; b0 < B; b0 += sc.group) {
         const int nb = (B - b0 < sc.group) ? B - b0 : sc.group;
         const bf16_t* q = sc.qk + (long long)b0 * S * 2 * C;
+        bool frag_pv = false;                         // P written in fragment order and consumed by attn_pv.hip
         // s = q k^T / sqrt(C), [nb][S][ld]
         a.X = q; a.W = q + C; a.bias = nullptr; a.bias_mode = 0; a.out_bf16 = nullptr; a.out_f32 = nullptr; a.out_f16 = nullptr;
         a.Win = a.Wout = S; a.Cin = C; a.Cout = ld; a.Wrows = S; a.ldx = 2 * C; a.ldw = 2 * C; a.ldo = lp;
@@ -581,6 +588,8 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
             k.mode = 1; k.rowout = shift; k.gate = gate; k.gate_expect = 1;
             HIPCK(c, vt_launch_attn_qk(k, s), "attn row max");
             k.mode = 2; k.P = sc.probs; k.ldp = lp; k.p_bs = (long long)S * lp; k.rowin = shift; k.rowout = rinv; k.gate = nullptr;
+            frag_pv = c->attn_pv_kernel && vt_attn_pv_supported(S, C);
+            if (frag_pv) { k.p_frag = 1; k.p_bs = vt_attn_pt_elems(S); }
             if (c->profiling) {
                 vt_context::ProfRec r;
                 r.e0 = c->next_event(); r.e1 = c->next_event();
@@ -607,6 +616,26 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
             a.row_mode = 2; a.row_in = shift; a.out_bf16 = sc.probs; a.gate = nullptr;
             HIPCK(c, launch_gemm(c, a, s), "attn exp scores");
             HIPCK(c, vt_launch_attn_row_reduce(sc.part, slots, S, S, nb, 1, rinv, nullptr, 0, s), "attn row sums");
+        }
+        if (frag_pv) {
+            AttnPvArgs v{};
+            v.Pt = sc.probs; v.pt_bs = vt_attn_pt_elems(S); v.vt = sc.vt + (long long)b0 * C * lp; v.ldv = lp; v.vt_bs = (long long)C * lp;
+            v.rinv = rinv; v.row_bs = S; v.o = sc.o + (long long)b0 * S * C; v.ldo = C; v.o_bs = (long long)S * C;
+            v.S = S; v.C = C; v.batch = nb; v.zeros = c->zeros;
+            if (c->profiling) {
+                vt_context::ProfRec r;
+                r.e0 = c->next_event(); r.e1 = c->next_event();
+                if (!r.e0 || !r.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+                r.flops = 2.0 * nb * (double)S * S * C;
+                r.cfg = VT_PROF_ATTN_PV;
+                HIPCK(c, hipEventRecord(r.e0, s), "hipEventRecord");
+                HIPCK(c, vt_launch_attn_pv(v, s), "attn pv");
+                HIPCK(c, hipEventRecord(r.e1, s), "hipEventRecord");
+                c->prof.push_back(r);
+            } else {
+                HIPCK(c, vt_launch_attn_pv(v, s), "attn pv");
+            }
+            continue;
         }
         // o = P v -> bf16 [nb][S][C]   (rows of P~ scaled by 1 / row sum in the epilogue)
         a.X = sc.probs; a.W = sc.vt + (long long)b0 * C * lp; a.out_f16 = nullptr; a.out_bf16 = sc.o + (long long)b0 * S * C;
@@ -1170,6 +1199,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 9) { c->attn_qk_kernel = value != 0; return VT_OK; }
     if (flag == 10) { c->pv_stream = value != 0; return VT_OK; }
     if (flag == 11) { c->fp8 = value != 0; return VT_OK; }
+    if (flag == 12) { c->attn_pv_kernel = value != 0; return VT_OK; }
     if (flag == 7) {
         if (value < 0 || value > 2) return c->fail(VT_ERR_INVALID, "vt_set_flag(7): value %d not in 0..2", value);
         c->attn_mode = value;

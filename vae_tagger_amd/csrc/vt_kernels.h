@@ -49,14 +49,16 @@ const char* vt_conv_gemm_config_name(int cfg);
 // profile slots: 0..2 conv_gemm tiles, 3..8 conv3x3_halo variants, 9 conv_gemm two-workgroups-per-CU tile, 10 attn_qk, 11 fp8 halo conv
 constexpr int VT_PROF_ATTN_QK = 10;
 constexpr int VT_PROF_HALO_FP8 = 11;
-constexpr int VT_PROF_GN_APPLY = 12;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
-constexpr int VT_NUM_PROF_SLOTS = 13;
+constexpr int VT_PROF_ATTN_PV = 12;
+constexpr int VT_PROF_GN_APPLY = 13;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 14;
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
     const bf16_t* q; const bf16_t* k;   // row-major [S][ldq] bf16 (the q | k buffer: ldq = 2 C), batch stride qk_bs
     int S, C, ldq; long long qk_bs;
     bf16_t* P; int ldp; long long p_bs; // mode 2: [S][ldp] bf16 out, columns [S, ldp) written as 0
+    int p_frag;                         // mode 2: 1 = P is written in MFMA fragment order for attn_pv.hip (ldp unused, p_bs = vt_attn_pt_elems)
     const float* rowin;                 // mode 2: per-row exponent shift [batch][row_bs]
     float* rowout;                      // mode 1: row maxima of alpha q.k; mode 2: 1 / row sum   [batch][row_bs]
     long long row_bs;
@@ -68,6 +70,22 @@ struct AttnQkArgs {
 };
 bool vt_attn_qk_supported(int S, int C);
 hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s);
+
+// P.V with P in attn_qk's fragment order (attn_pv.hip; d = 512 only): o[q][c] = rinv[q] * sum_k P[q][k] v^T[c][k]
+struct AttnPvArgs {
+    const bf16_t* Pt; long long pt_bs;  // fragment-ordered P: [slab of 32 queries][64-key tile][piece j*2+h][lane][8] bf16
+    const bf16_t* vt; int ldv; long long vt_bs;   // v^T [C][ldv] bf16 (keys contiguous; keys [S, round8(S)) zero)
+    const float* rinv; long long row_bs;          // 1 / row sum, [batch][row_bs]
+    bf16_t* o; int ldo; long long o_bs;           // [S][ldo] bf16
+    int S, C, batch;
+    const void* zeros;
+};
+bool vt_attn_pv_supported(int S, int C);
+// elements between consecutive 32-query slabs of the fragment-ordered P: key tiles x 4 pieces x 512, plus 2304 B so that the
+// eight waves of a workgroup (same key tile, consecutive slabs) do not all hit one HBM channel at a power-of-two stride
+__host__ __device__ inline long long vt_attn_pt_slab_stride(int S) { return (long long)((S + 63) / 64) * 2048 + 1152; }
+long long vt_attn_pt_elems(int S);
+hipError_t vt_launch_attn_pv(const AttnPvArgs& a, hipStream_t s);
 
 // 3x3 stride-1 pad-1 conv, halo-tile kernel (conv3x3_halo.hip)
 struct Conv3x3Args {
