@@ -137,10 +137,13 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         do not displace the rest of the working set from L2 / Infinity Cache; 0 = default policy.
  * flag 12: 1 (default) = with flag 9, Q.K^T stores the probabilities in the MFMA fragment order it holds them in and P.V runs on its
  *         own kernel that loads them straight into registers (only v^T passes through LDS); 0 = row-major P + the generic GEMM.
- * flag 11: 1 = BASELINE.json configs[4]: the 20 stride-1 3x3 resnet convolutions run on fp8 (OCP e4m3) operands on the fp8 MFMA
- *         (v_mfma_scale_f32_32x32x64_f8f6f4, 2x the bf16 rate): weights e4m3 with per-output-channel scales, activations e4m3(8 x)
- *         written by the GroupNorm-apply pass; fp32 accumulate, everything else unchanged.  OPT-IN, for tagging only: latents move
- *         by ~1e-1 (max; rms 2e-2), logits stay within 1e-2 of the CPU reference (tests/diagnostics/fp8_study.py).  0 (default) = bf16.
+ * flag 11: 1 = BASELINE.json configs[4]: all 23 3x3 convolutions of the resnet / downsample stack run on fp8 (OCP e4m3) operands on
+ *         the fp8 MFMA (2x the bf16 rate): the 20 stride-1 convs on v_mfma_scale_f32_32x32x64_f8f6f4 (conv3x3_halo_fp8.hip), the
+ *         three stride-2 convs on v_mfma_scale_f32_16x16x128_f8f6f4 (conv_gemm.hip, F8).  Weights e4m3 with per-output-channel
+ *         scales; activations e4m3(8 x) written by the GroupNorm-apply pass, the block output feeding a stride-2 conv e4m3(x);
+ *         fp32 accumulate; conv_in, conv_out, the 1x1 shortcuts and the attention stay bf16 / fp32.  OPT-IN, for tagging only:
+ *         latents move by ~1e-1 (max; rms 2e-2), logits stay within 1e-2 of the CPU reference (measured 4.4e-3;
+ *         tests/diagnostics/fp8_study.py).  0 (default) = bf16.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 
@@ -180,7 +183,8 @@ int vt_op_conv2d_gn(vt_context* ctx, const void* x_bf16_nhwc, const void* w_bf16
  * encoder quantises them (x -> e4m3(8 x), w -> e4m3 with per-cout absmax scales); out fp32 NHWC.  Cin % 64 == 0, Cout % 128 == 0. */
 size_t vt_op_conv3x3_fp8_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int vt_op_conv3x3_fp8(vt_context* ctx, const float* x_f32_nhwc, const float* w_f32_oihw, const float* bias, const float* residual_f32,
-                      float* out_f32, int B, int H, int W, int Cin, int Cout, void* workspace, void* stream);
+                      float* out_f32, int B, int H, int W, int Cin, int Cout, int stride /* 1: pad 1; 2: pad (0,1,0,1), x -> e4m3(x) */,
+                      void* workspace, void* stream);
 int vt_op_gemm_nt(vt_context* ctx, const void* a_bf16, const void* b_bf16, const float* bias, float* out_f32,
                   void* out_bf16, int batch, int M, int N, int K, int lda, int ldb, int ldo, long long a_bs,
                   long long b_bs, long long o_bs, float alpha, int bias_per_row, void* stream);

@@ -107,7 +107,7 @@ class Ops:
         torch.cuda.synchronize()
         return nchw(o32.cpu()), ss.cpu()
 
-    def conv3x3_fp8(self, x_nchw, w_oihw, bias=None, residual_nchw=None):
+    def conv3x3_fp8(self, x_nchw, w_oihw, bias=None, residual_nchw=None, stride=1):
         """x, w fp32 -> fp32 NCHW result of the fp8 (e4m3) halo conv; operands are quantised inside the call exactly as the
         encoder quantises them with vt_set_flag(ctx, 11, 1)."""
         B, Cin, H, W = x_nchw.shape
@@ -116,12 +116,12 @@ class Ops:
         w = w_oihw.to(self.dev, torch.float32).contiguous()
         b = bias.to(self.dev, torch.float32).contiguous() if bias is not None else None
         r = nhwc(residual_nchw).to(self.dev, torch.float32) if residual_nchw is not None else None
-        out = torch.full((B, H, W, Cout), float("nan"), device=self.dev, dtype=torch.float32)
+        out = torch.full((B, H // stride, W // stride, Cout), float("nan"), device=self.dev, dtype=torch.float32)
         n = self.ctx.lib.vt_op_conv3x3_fp8_workspace_bytes(B, H, W, Cin, Cout)
         assert n > 0
         ws = torch.empty(n + 256, device=self.dev, dtype=torch.uint8)
         ptr = (ws.data_ptr() + 255) // 256 * 256
-        self.ctx.call("vt_op_conv3x3_fp8", vp(x), vp(w), vp(b), vp(r), vp(out), B, H, W, Cin, Cout, ctypes.c_void_p(ptr), self.stream)
+        self.ctx.call("vt_op_conv3x3_fp8", vp(x), vp(w), vp(b), vp(r), vp(out), B, H, W, Cin, Cout, stride, ctypes.c_void_p(ptr), self.stream)
         torch.cuda.synchronize()
         return nchw(out.cpu())
 

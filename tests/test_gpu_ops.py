@@ -233,3 +233,19 @@ def test_fp8_conv_matches_torch_on_the_same_quantised_operands(ops, B, Cin, Cout
     x[0, 0, 1, 1] = 100.0                       # saturates at 448 / 8: the clamp is part of the contract
     got = ops.conv3x3_fp8(x, w)
     assert torch.allclose(got, ref_of(x), rtol=1e-4, atol=3e-3), (got - ref_of(x)).abs().max()
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 128, 34, 50), (1, 256, 16, 16), (1, 512, 18, 22)])
+def test_fp8_stride2_conv_matches_torch_on_the_same_quantised_operands(ops, B, C, H, W):
+    """Downsample2D's conv (pad (0,1,0,1), stride 2) on e4m3 operands: conv_gemm_kernel<..., F8> with
+    v_mfma_scale_f32_16x16x128_f8f6f4 (the fp8 mode's stride-2 convs).  The un-normalised residual stream is quantised as e4m3(x)."""
+    x = 3.0 * _rand((B, C, H, W), 5)
+    w = _rand((C, C, 3, 3), 6, (C * 9) ** -0.5)
+    b = _rand((C,), 7, 0.1)
+    sc = w.abs().amax(dim=(1, 2, 3), keepdim=True) / 448.0
+    wq = _e4m3(w / sc) * sc
+    ref = F.conv2d(F.pad(_e4m3(x), (0, 1, 0, 1)), wq, b, stride=2)
+    res = _rand(tuple(ref.shape), 8)
+    got = ops.conv3x3_fp8(x, w, b, residual_nchw=res, stride=2)
+    assert got.shape == ref.shape
+    assert torch.allclose(got, ref + res, rtol=1e-4, atol=2e-3), (got - ref - res).abs().max()

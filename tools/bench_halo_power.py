@@ -49,7 +49,7 @@ def run8(B, H, W, Cin, Cout, fill, iters=10):
     ws = torch.empty(n + 256, device=dev, dtype=torch.uint8)
     ptr = (ws.data_ptr() + 255) // 256 * 256
     def call():
-        ctx.call("vt_op_conv3x3_fp8", vp(x), vp(w), None, None, vp(out), B, H, W, Cin, Cout, ctypes.c_void_p(ptr), None)
+        ctx.call("vt_op_conv3x3_fp8", vp(x), vp(w), None, None, vp(out), B, H, W, Cin, Cout, 1, ctypes.c_void_p(ptr), None)
     for _ in range(10): call()
     torch.cuda.synchronize()
     ns = ctx.lib.vt_profile_num_configs()

@@ -19,7 +19,7 @@ n = ops.ctx.lib.vt_op_conv3x3_fp8_workspace_bytes(B, H, W, Cin, Cout)
 ws = torch.zeros(n + 256, device="cuda", dtype=torch.uint8)
 ptr = (ws.data_ptr() + 255) // 256 * 256
 off = ptr - ws.data_ptr()
-ops.ctx.call("vt_op_conv3x3_fp8", vp(xd), vp(wd), None, None, vp(out), B, H, W, Cin, Cout, ctypes.c_void_p(ptr), ctypes.c_void_p(0))
+ops.ctx.call("vt_op_conv3x3_fp8", vp(xd), vp(wd), None, None, vp(out), B, H, W, Cin, Cout, 1, ctypes.c_void_p(ptr), ctypes.c_void_p(0))
 torch.cuda.synchronize()
 x8 = ws[off:off + B * H * W * Cin].cpu()
 ref8 = e4(nhwc(x) * 8.0).view(torch.uint8).flatten()

@@ -49,7 +49,7 @@ PROTOTYPES = {
     "vt_op_conv2d_gn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vt_op_conv2d_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "vt_op_conv3x3_fp8_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "vt_op_conv3x3_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vt_op_conv3x3_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vt_op_gemm_nt": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _f, _i, _vp]),
     "vt_op_conv_in": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "vt_op_groupnorm_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -25,6 +25,7 @@ struct HostTensor {
 struct ConvW {
     const bf16_t* w = nullptr; const bf16_t* wp = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0;   // w: [cout][tap][cin]; wp: halo-kernel packing
     const unsigned char* wp8 = nullptr; const float* mult8 = nullptr;   // fp8 halo kernel: e4m3 weights / per-cout (scale / act_scale)
+    const unsigned char* w8g = nullptr; const float* mult8g = nullptr;  // fp8 generic GEMM (stride-2 convs): [cout][tap][cin] e4m3 / per-cout scale (input scale 1)
 };
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
 struct ResnetW {
@@ -87,6 +88,7 @@ uint8_t f2e4m3(float f) {
     return sgn | (uint8_t)((biased << 3) | M);
 }
 constexpr float FP8_ACT_SCALE = 8.0f;      // activations are stored as e4m3(8 x): |silu(GroupNorm)| up to 56 before saturation
+constexpr float FP8_RES_SCALE = 1.0f;      // the un-normalised residual stream feeding a stride-2 conv is stored as e4m3(x): |x| up to 448
 
 // e4m3 packing of a 3x3 conv for conv3x3_halo_fp8.hip: Wp8[cin/64][step (kx-major)][cout row][64] + mult[cout] = scale / act_scale
 void pack_conv_fp8(const float* w_oihw, int cout, int cin, std::vector<uint8_t>* wp8, std::vector<float>* mult) {
@@ -224,6 +226,19 @@ int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, C
         out->wp8 = (const unsigned char*)c->upload(p8.data(), p8.size());
         out->mult8 = (const float*)c->upload(m8.data(), m8.size() * 4);
         if (!out->wp8 || !out->mult8) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+        // the generic fp8 GEMM's layout: [cout][tap][cin] e4m3 with the same per-cout scales (its input carries FP8_RES_SCALE)
+        std::vector<uint8_t> g8((size_t)cout * 9 * cin);
+        std::vector<float> mg(cout);
+        for (int o = 0; o < cout; ++o) {
+            const float sc = m8[o] * FP8_ACT_SCALE;
+            mg[o] = sc / FP8_RES_SCALE;
+            for (int i = 0; i < cin; ++i)
+                for (int t = 0; t < 9; ++t)
+                    g8[((size_t)o * 9 + t) * cin + i] = f2e4m3(w->v[((size_t)o * cin + i) * 9 + t] / sc);
+        }
+        out->w8g = (const unsigned char*)c->upload(g8.data(), g8.size());
+        out->mult8g = (const float*)c->upload(mg.data(), mg.size() * 4);
+        if (!out->w8g || !out->mult8g) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
     }
     return VT_OK;
 }
@@ -408,7 +423,7 @@ struct ScFuse { const bf16_t* x; const bf16_t* wp; const float* bias; int cin; c
 int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int Win, int stride, int pad, int Hout,
              int Wout, const void* res, void* oh, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32,
              const float* xnorm_f32 = nullptr, const float* ss = nullptr, int rdt = 1, const ScFuse* sc = nullptr,
-             bool x_fp8 = false) {
+             bool x_fp8 = false, bool o16_e4m3 = false) {
     const float* res32 = rdt == 1 ? (const float*)res : nullptr;
     const f16_t* res16 = rdt == 2 ? (const f16_t*)res : nullptr;
     float* o32 = rdt == 1 ? (float*)oh : nullptr;
@@ -416,11 +431,41 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     const int cpg = w.cout / groups;
     const bool fuse = gn && c->fuse_gn_stats && (cpg == 4 || cpg == 8 || cpg == 16);
     if (gn) gn->parts = 0;
+    if (x_fp8 && stride == 2) {
+        // stride-2 conv on e4m3 operands: the generic implicit GEMM with the fp8 MFMA (x = e4m3(FP8_RES_SCALE * h))
+        if (!w.w8g || w.k != 3 || ss || sc || o16_e4m3) return c->fail(VT_ERR_STATE, "internal: fp8 operands requested for a conv the fp8 GEMM cannot run");
+        ConvGemmArgs a{};
+        a.X = (const bf16_t*)x; a.W = (const bf16_t*)w.w8g; a.f8 = 1; a.col_scale = w.mult8g;
+        a.bias = w.b; a.res = res32; a.res_f16 = res16; a.out_f32 = o32; a.out_f16 = oh16; a.out_bf16 = o16; a.zeros = c->zeros;
+        a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cin = w.cin; a.Cout = w.cout; a.Wrows = w.cout;
+        a.ksize = 3; a.stride = 2; a.pad = pad;
+        a.ldx = w.cin; a.ldw = 9 * w.cin; a.ldo = w.cout; a.ldr = w.cout;
+        a.x_bs = (long long)Hin * Win * w.cin; a.w_bs = 0; a.o_bs = (long long)Hout * Wout * w.cout; a.r_bs = a.o_bs;
+        a.batch = B; a.alpha = 1.f; a.bias_mode = 1; a.out_mode = 0; a.short_tiles = c->gemm_short;
+        if (fuse && w.cout > 32 && (w.cout % (w.cout <= 128 ? 128 : 256)) == 0) {
+            a.gn_partial = gn->partial; a.gn_cpg = cpg; gn->parts = vt_conv_gemm_ptiles_of(a);
+        }
+        if (c->profiling) {
+            vt_context::ProfRec r;
+            r.e0 = c->next_event(); r.e1 = c->next_event();
+            if (!r.e0 || !r.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+            r.flops = 2.0 * B * (double)Hout * Wout * w.cout * 9.0 * w.cin;
+            r.cfg = VT_PROF_GEMM_FP8;
+            HIPCK(c, hipEventRecord(r.e0, s), "hipEventRecord");
+            HIPCK(c, vt_launch_conv_gemm(a, s), "conv_gemm_fp8");
+            HIPCK(c, hipEventRecord(r.e1, s), "hipEventRecord");
+            c->prof.push_back(r);
+        } else {
+            HIPCK(c, vt_launch_conv_gemm(a, s), "conv_gemm_fp8");
+        }
+        return VT_OK;
+    }
     if (x_fp8) {
         if (!w.wp8 || w.k != 3 || stride != 1 || pad != 1 || ss || (sc && !sc->wp8)) return c->fail(VT_ERR_STATE, "internal: fp8 operands requested for a conv the fp8 kernel cannot run");
         Conv3x3Fp8Args h{};
         h.X = (const unsigned char*)x; h.Wp = w.wp8; h.mult = w.mult8; h.bias = w.b; h.res = res32; h.res_f16 = res16;
-        h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
+        h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16_e4m3 ? nullptr : o16; h.zeros = c->zeros;
+        if (o16_e4m3) { h.out_e4m3 = (unsigned char*)o16; h.out_e4m3_scale = FP8_RES_SCALE; }
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
         if (sc) { h.scX = sc->x; h.scW = sc->wp8; h.scCin = sc->cin; h.bias = sc->bias; }
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_fp8_tiles(Hin, Win); }
@@ -463,12 +508,13 @@ bool norm_conv_fusable(const vt_context* c, const ConvW& w, int cin) {
 // x: the tensor to normalise (xdt 0 = bf16 conv output, 1 = fp32 / 2 = fp16 residual stream); res / oh: residual in / out (rdt).
 int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, int xdt, int B, int H, int W,
                   int groups, bf16_t* act, const void* res, void* oh, bf16_t* o16, GnState& gn, bool want_stats,
-                  hipStream_t s, int rdt, const ScFuse* sc = nullptr) {
+                  hipStream_t s, int rdt, const ScFuse* sc = nullptr, bool o16_e4m3 = false) {
     const bool f8 = c->fp8 && w.wp8 && w.k == 3 && (!sc || sc->wp8);      // fp8 operands: the GroupNorm-apply pass writes e4m3, the conv reads it
+    if (o16_e4m3 && !f8) return c->fail(VT_ERR_STATE, "internal: e4m3 output requested from a bf16 conv");
     if (f8 || xdt == 2 || !norm_conv_fusable(c, w, n.c)) {   // (the fused staging reads fp32 or bf16 only)
         int r = run_gn(c, x, xdt, B, H * W, n, groups, 1, act, gn, s, f8);
         if (r) return r;
-        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt, sc, f8);
+        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt, sc, f8, o16_e4m3);
     }
     if (sc) return c->fail(VT_ERR_STATE, "internal: fused shortcut with the fused-norm staging");
     int parts = gn.parts;
@@ -931,7 +977,8 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
         return c->fuse_shortcut && rw.sc_wp && c->use_halo_conv && rw.c2.wp && !c->fuse_gn_apply && (!(c->fp8 && rw.c2.wp8) || rw.sc_wp8);
     };
     // one ResnetBlock2D: h <- conv2(silu(gn(conv1(silu(gn(h)))))) + shortcut(h)
-    auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out) -> int {
+    // hb_e4m3: the stage's downsample conv runs on fp8 operands, so the block output for it is written as e4m3 instead of bf16
+    auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out, bool hb_e4m3 = false) -> int {
         const int nxt = (cur + 1) % 3, scb = (cur + 2) % 3;
         const void* res = f32[cur];
         int rr;
@@ -955,7 +1002,7 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
                                 c1h ? nullptr : tmid, gn, true, s, rdt))) return rr;
         if (want_bf16_out) {
             // the only consumer is the downsample conv (bf16 operand, no norm): skip the fp32 copy of h and the stats
-            return run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt, sc);
+            return run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt, sc, hb_e4m3);
         }
         if ((rr = run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, f32[nxt], nullptr, gn, true, s, rdt, sc))) return rr;
         cur = nxt;
@@ -963,12 +1010,16 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
     };
 
     const bf16_t* h16 = nullptr;                   // bf16 copy of the current h, when one exists
+    bool hb_is_e4m3 = false;
     for (size_t i = 0; i < e.stages.size(); ++i) {
         const StageW& st = e.stages[i];
         for (size_t j = 0; j < st.res.size(); ++j) {
             const bool last = j + 1 == st.res.size();
             if (st.res[j].has_sc && !h16) return c->fail(VT_ERR_STATE, "internal: shortcut conv without a bf16 input");
-            if ((r = resnet(st.res[j], h16, last && st.has_down))) return r;
+            // fp8 mode: the last block of a stage hands its output to the stride-2 conv as e4m3 when both run on fp8 operands
+            const bool down8 = last && st.has_down && c->fp8 && st.down.w8g && st.res[j].c2.wp8 && !st.res[j].has_sc;
+            if ((r = resnet(st.res[j], h16, last && st.has_down, down8))) return r;
+            if (last) hb_is_e4m3 = down8;
             h16 = (last && st.has_down) ? hb : nullptr;
         }
         if (st.has_down) {
@@ -980,7 +1031,7 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             // before conv1 overwrites tmid; when the shortcut is fused into conv2 it must outlive conv1, so it goes to the
             // third rotating buffer (the block's `scb`, free now that no shortcut tensor is written)
             bf16_t* copy = !next_has_sc ? nullptr : (fuse_sc(e.stages[i + 1].res[0]) ? (bf16_t*)f32[(nxt + 2) % 3] : tmid);
-            if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], copy, s, &gn, e.groups, nullptr, nullptr, rdt))) return r;
+            if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], copy, s, &gn, e.groups, nullptr, nullptr, rdt, nullptr, hb_is_e4m3))) return r;
             h16 = copy;
             cur = nxt; h = ho; w = wo;
         }
@@ -1458,11 +1509,11 @@ size_t vt_op_conv3x3_fp8_workspace_bytes(int B, int H, int W, int Cin, int Cout)
 // to e4m3(8 x) by the GroupNorm-apply kernel (identity affine, no SiLU), w (fp32 OIHW, DEVICE; copied to the host, packed to e4m3
 // with per-cout scales and written into the workspace: synchronises).  out = conv(deq(x8), deq(w8)) + bias (+ residual), fp32 NHWC.
 int vt_op_conv3x3_fp8(vt_context* c, const float* x_nhwc, const float* w_oihw, const float* bias, const float* res, float* o32,
-                      int B, int H, int W, int Cin, int Cout, void* ws, void* stream) {
+                      int B, int H, int W, int Cin, int Cout, int stride, void* ws, void* stream) {
     if (!c) return VT_ERR_INVALID;
     DeviceGuard guard(c);
     if (!x_nhwc || !w_oihw || !o32 || !ws || ((uintptr_t)ws % ALIGN)) return c->fail(VT_ERR_INVALID, "vt_op_conv3x3_fp8: bad buffer");
-    if (vt_op_conv3x3_fp8_workspace_bytes(B, H, W, Cin, Cout) == 0) return c->fail(VT_ERR_INVALID, "vt_op_conv3x3_fp8: unsupported shape");
+    if (vt_op_conv3x3_fp8_workspace_bytes(B, H, W, Cin, Cout) == 0 || (stride != 1 && stride != 2)) return c->fail(VT_ERR_INVALID, "vt_op_conv3x3_fp8: unsupported shape");
     hipStream_t s = (hipStream_t)stream;
     char* p = (char*)ws;
     unsigned char* x8 = (unsigned char*)p; p += align_up((size_t)B * H * W * Cin);
@@ -1477,6 +1528,22 @@ int vt_op_conv3x3_fp8(vt_context* c, const float* x_nhwc, const float* w_oihw, c
     HIPCK(c, hipMemcpy(w8, p8.data(), p8.size(), hipMemcpyHostToDevice), "vt_op_conv3x3_fp8 copy");
     HIPCK(c, hipMemcpy(mult, m8.data(), m8.size() * 4, hipMemcpyHostToDevice), "vt_op_conv3x3_fp8 copy");
     HIPCK(c, hipMemcpy(ss, hss.data(), hss.size() * 4, hipMemcpyHostToDevice), "vt_op_conv3x3_fp8 copy");
+    if (stride == 2) {
+        // Downsample2D's conv: pad (0,1,0,1), stride 2, on the generic GEMM's fp8 variant; x is quantised as e4m3(x) (scale 1)
+        std::vector<uint8_t> g8((size_t)Cout * 9 * Cin);
+        std::vector<float> mg(Cout);
+        for (int o = 0; o < Cout; ++o) {
+            const float sc = m8[o] * FP8_ACT_SCALE;
+            mg[o] = sc / FP8_RES_SCALE;
+            for (int i = 0; i < Cin; ++i)
+                for (int t = 0; t < 9; ++t) g8[((size_t)o * 9 + t) * Cin + i] = f2e4m3(hw[((size_t)o * Cin + i) * 9 + t] / sc);
+        }
+        HIPCK(c, hipMemcpy(w8, g8.data(), g8.size(), hipMemcpyHostToDevice), "vt_op_conv3x3_fp8 copy");
+        HIPCK(c, hipMemcpy(mult, mg.data(), mg.size() * 4, hipMemcpyHostToDevice), "vt_op_conv3x3_fp8 copy");
+        HIPCK(c, vt_launch_gn_apply(x_nhwc, 1, ss, x8, B, H * W, Cin, 0, s, FP8_RES_SCALE), "vt_op_conv3x3_fp8 quantise");
+        ConvW cw; cw.cin = Cin; cw.cout = Cout; cw.k = 3; cw.w8g = w8; cw.mult8g = mult; cw.b = bias;
+        return run_conv(c, cw, (const bf16_t*)x8, B, H, W, 2, 0, H / 2, W / 2, res, o32, nullptr, s, nullptr, 32, nullptr, nullptr, 1, nullptr, true);
+    }
     HIPCK(c, vt_launch_gn_apply(x_nhwc, 1, ss, x8, B, H * W, Cin, 0, s, FP8_ACT_SCALE), "vt_op_conv3x3_fp8 quantise");
     Conv3x3Fp8Args h{};
     h.X = x8; h.Wp = w8; h.mult = mult; h.bias = bias; h.res = res; h.out_f32 = o32; h.zeros = c->zeros;

@@ -333,6 +333,19 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
                     *(f16x8*)(a.out_f16 + o + 8 * i) = hh;
                 }
             }
+            if (a.out_e4m3) {
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                i32x4 o8 = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_fmed3f(acc[h][j][4 * i + q] * a.out_e4m3_scale, -448.f, 448.f);
+                    o8[i] = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], o8[i], false);
+                    o8[i] = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], o8[i], true);
+                }
+                *(i32x4*)(a.out_e4m3 + o) = o8;
+            }
             if (a.out_bf16) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -412,7 +425,7 @@ int vt_halo_fp8_row_of_cout(int cout_local /*0..31*/) {
 }
 
 hipError_t vt_launch_conv3x3_halo_fp8(const Conv3x3Fp8Args& a, hipStream_t s) {
-    if (!a.X || !a.Wp || !a.mult || !a.zeros || (!a.out_f32 && !a.out_bf16 && !a.out_f16)) return hipErrorInvalidValue;
+    if (!a.X || !a.Wp || !a.mult || !a.zeros || (!a.out_f32 && !a.out_bf16 && !a.out_f16 && !a.out_e4m3)) return hipErrorInvalidValue;
     if ((a.res && a.res_f16) || (a.res_f16 && a.out_f32)) return hipErrorInvalidValue;
     if (!vt_conv3x3_halo_fp8_supported(a.Cin, a.Cout) || a.batch <= 0 || a.H <= 0 || a.W <= 0) return hipErrorInvalidValue;
     if (a.gn_partial && a.gn_cpg != 4 && a.gn_cpg != 8 && a.gn_cpg != 16) return hipErrorInvalidValue;

@@ -25,15 +25,20 @@
 
 namespace {
 
-constexpr int BK = 64;            // k-values per K-step (128-B LDS rows)
-constexpr int ROWB = BK * 2;      // bytes per LDS row
+constexpr int ROWB = 128;         // bytes per LDS row = one K-step of a row: 64 bf16 or (F8) 128 e4m3 k-values
 
 // OCC2: compiled for two workgroups per CU (<= 128 VGPRs; the launcher checks the LDS fits twice): the latency-bound
 // short-K launches (1x1 shortcuts, attention projections, Q.K^T) overlap one workgroup's prologue / epilogue with the other's MFMAs.
 // one output tile; `logical` = tile index in [0, ptiles * ctiles * batch)
-template <int BP, int BC, int WP, int WC>
+// F8: both operands are OCP e4m3 bytes (a.X / a.W reinterpreted; every "element" offset is then a byte offset) and a K-step is
+// ONE v_mfma_scale_f32_16x16x128_f8f6f4 per tile pair (both scales 2^0) instead of two v_mfma_f32_16x16x32_bf16: the same LDS and
+// DMA bytes per K-step carry twice the K, which is what a fill-bound tile needs (the stride-2 convs of the fp8 mode, flag 11).
+template <int BP, int BC, int WP, int WC, bool F8 = false>
 __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem, int logical) {
     static_assert(WP * WC == 8, "8 waves per workgroup");
+    constexpr int ES = F8 ? 1 : 2;            // bytes per element
+    constexpr int BK = ROWB / ES;             // k-values per K-step
+    constexpr int CE = 16 / ES;               // elements per 16-B DMA chunk
     constexpr int TP = BP / WP / 16;          // 16-pixel MFMA tiles per wave
     constexpr int TC = BC / WC / 16;          // 16-cout MFMA tiles per wave
     constexpr int XI = BP / 8;                // DMA wave-instructions per X tile (8 rows each)
@@ -56,8 +61,8 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
     const int p0 = (logical / ctiles) * BP;
     const int c0 = (logical % ctiles) * BC;
 
-    const bf16_t* Xb = a.X + (long long)b * a.x_bs;
-    const bf16_t* Wb = a.W + (long long)b * a.w_bs;
+    const char* Xb = (const char*)a.X + (long long)b * a.x_bs * ES;
+    const char* Wb = (const char*)a.W + (long long)b * a.w_bs * ES;
 
     // ---- per-lane DMA bookkeeping.  Lane l of a wave-instruction writes LDS row (l>>3), physical
     // chunk (l&7); the logical chunk it must fetch is (l&7) ^ (row&7) = (l&7) ^ (l>>3).
@@ -76,7 +81,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
         const bool rv = (r < BP) && (p < HWo);
         const int oy = p / a.Wout, ox = p - oy * a.Wout;
         const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-        xoff[j] = (iy0 * a.Win + ix0) * a.ldx + lchunk * 8;
+        xoff[j] = (iy0 * a.Win + ix0) * a.ldx + lchunk * CE;
         unsigned m = 0;
         if (rv) {
             for (int t = 0; t < ntaps; ++t) {
@@ -97,7 +102,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
         const int rl = rblk * 8 + lrow;
         const int n = c0 + (TC == 4 ? (rl & ~63) + (rl & 3) + 4 * ((rl >> 4) & 3) + 16 * ((rl >> 2) & 3) : rl);
         wvalid[j] = (rblk < WI) && (n < a.Wrows);
-        woff[j] = n * a.ldw + lchunk * 8;
+        woff[j] = n * a.ldw + lchunk * CE;
     }
 
     auto stage = [&](int tap, int cb, int buf) {
@@ -106,13 +111,13 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
         const int ky = (tap * 11) >> 5, kx = tap - ky * 3;      // tap < 9
         const int doff = (a.ksize == 1) ? 0 : (ky * a.Win + kx) * a.ldx;
         const int k0 = cb * BK;
-        const bool cv = !chunk_tail_possible || (k0 + lchunk * 8 < a.Cin);
+        const bool cv = !chunk_tail_possible || (k0 + lchunk * CE < a.Cin);
 #pragma unroll
         for (int j = 0; j < NXJ; ++j) {
             const int rblk = j * 8 + wave;
             if (XI % 8 == 0 || rblk < XI) {
                 const bool v = ((xmask[j] >> tap) & 1u) && cv;
-                const void* src = v ? (const void*)(Xb + (xoff[j] + doff + k0)) : a.zeros;
+                const void* src = v ? (const void*)(Xb + (long long)(xoff[j] + doff + k0) * ES) : a.zeros;
                 if (a.x_stream) __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(xs + rblk * 1024), 16, 0, 2);   // nt
                 else __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(xs + rblk * 1024), 16, 0, 0);
             }
@@ -122,7 +127,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
             const int rblk = j * 8 + wave;
             if (WI % 8 == 0 || rblk < WI) {
                 const bool v = wvalid[j] && cv;
-                const void* src = v ? (const void*)(Wb + (woff[j] + tap * a.Cin + k0)) : a.zeros;
+                const void* src = v ? (const void*)(Wb + (long long)(woff[j] + tap * a.Cin + k0) * ES) : a.zeros;
                 __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(ws + rblk * 1024), 16, 0, 0);
             }
         }
@@ -154,19 +159,42 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
         }
         const char* xs = smem + (t & 1) * STAGE_BYTES + (wp * (BP / WP)) * ROWB;
         const char* ws = smem + (t & 1) * STAGE_BYTES + BP * ROWB + (wc * (BC / WC)) * ROWB;
+        if constexpr (F8) {
+            // lane (fq, frow): row frow, k = 32 fq .. + 31 = logical chunks 2 fq, 2 fq + 1 (physical ^ (row & 7))
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            typedef int i32x8 __attribute__((ext_vector_type(8)));
+            const int fa = frow * ROWB + (((2 * fq) ^ (lane & 7)) << 4), fb = frow * ROWB + (((2 * fq + 1) ^ (lane & 7)) << 4);
+            i32x8 wf[TC], xf[TP];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int fo = kk ? foff1 : foff0;
-            bf16x8 wf[TC], xf[TP];
+            for (int i = 0; i < TC; ++i) {
+                const i32x4 lo = *(const i32x4*)(ws + i * 16 * ROWB + fa), hi = *(const i32x4*)(ws + i * 16 * ROWB + fb);
+                wf[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
 #pragma unroll
-            for (int i = 0; i < TC; ++i) wf[i] = *(const bf16x8*)(ws + i * 16 * ROWB + fo);
-#pragma unroll
-            for (int j = 0; j < TP; ++j) xf[j] = *(const bf16x8*)(xs + j * 16 * ROWB + fo);
+            for (int j = 0; j < TP; ++j) {
+                const i32x4 lo = *(const i32x4*)(xs + j * 16 * ROWB + fa), hi = *(const i32x4*)(xs + j * 16 * ROWB + fb);
+                xf[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[i], xf[j], acc[i][j], 0, 0, 0, 127, 0, 127);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int fo = kk ? foff1 : foff0;
+                bf16x8 wf[TC], xf[TP];
+#pragma unroll
+                for (int i = 0; i < TC; ++i) wf[i] = *(const bf16x8*)(ws + i * 16 * ROWB + fo);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) xf[j] = *(const bf16x8*)(xs + j * 16 * ROWB + fo);
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
 
@@ -194,6 +222,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
             const int cg = cg0 + (TC == 4 ? i * 4 : i * 16);
             if (cg >= a.Cout) continue;
             f32x4 v = acc[i][j] * a.alpha;
+            if (a.col_scale) v *= *(const f32x4*)(a.col_scale + cg);       // e4m3 weights: per-cout scale / activation scale
             if (a.row_mode) {
                 if (a.row_mode == 3) {
                     v *= rin;
@@ -340,10 +369,10 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
     }
 }
 
-template <int BP, int BC, int WP, int WC, bool OCC2 = false>
+template <int BP, int BC, int WP, int WC, bool OCC2 = false, bool F8 = false>
 __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const ConvGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv_gemm_tile<BP, BC, WP, WC>(a, smem, vt_xcd_remap(blockIdx.x, gridDim.x));
+    conv_gemm_tile<BP, BC, WP, WC, F8>(a, smem, vt_xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Gated launches (a.gate: usually a no-op decided on the device) run as a small resident grid that walks the tiles, so a
@@ -356,6 +385,21 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_gated_kernel(cons
         conv_gemm_tile<BP, BC, WP, WC>(a, smem, t);
         __syncthreads();                                   // the epilogue may still be reading the stage buffers
     }
+}
+
+// fp8 launches (a.f8): plain grid only (no gated variant)
+template <int BP, int BC, int WP, int WC, bool OCC2 = false>
+hipError_t launch_cfg_f8(const ConvGemmArgs& a, hipStream_t s) {
+    constexpr int smem = 2 * (BP + BC) * ROWB;
+    static std::atomic<unsigned long long> attr_done{0};
+    auto kern = conv_gemm_kernel<BP, BC, WP, WC, OCC2, true>;
+    hipError_t ea = vt_once_per_device(attr_done, [&] { return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
+    if (ea != hipSuccess) return ea;
+    const int HWo = a.Hout * a.Wout;
+    const long long nblk = (long long)((HWo + BP - 1) / BP) * ((a.Cout + BC - 1) / BC) * a.batch;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), smem, s, a);
+    return hipGetLastError();
 }
 
 template <int BP, int BC, int WP, int WC, bool OCC2 = false>
@@ -387,7 +431,9 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
     if (!a.X || !a.W || !a.zeros) return hipErrorInvalidValue;
     if (a.ksize != 1 && a.ksize != 3) return hipErrorInvalidValue;
     if (a.Cin <= 0 || a.Cout <= 0 || a.batch <= 0 || a.Wrows <= 0 || a.Wrows > a.Cout) return hipErrorInvalidValue;
-    if ((a.ldx % 8) || (a.ldw % 8)) return hipErrorInvalidValue;          // 16-B aligned rows for the DMA
+    const int ce = a.f8 ? 16 : 8;                                          // elements per 16-B chunk
+    if ((a.ldx % ce) || (a.ldw % ce)) return hipErrorInvalidValue;        // 16-B aligned rows for the DMA
+    if (a.f8 && (a.gate || a.row_mode || a.x_stream || (a.Cin % 16) || (a.x_bs % 16) || (a.w_bs % 16))) return hipErrorInvalidValue;
     if (a.out_mode == 0 && ((a.ldo % 4) || (a.Cout % 4))) return hipErrorInvalidValue;
     if ((a.res || a.res_f16) && (a.ldr % 4)) return hipErrorInvalidValue;
     if (a.res && a.res_f16) return hipErrorInvalidValue;
@@ -405,6 +451,13 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
     // per-image offsets are 32-bit
     if ((long long)a.Hin * a.Win * a.ldx >= (1LL << 31)) return hipErrorInvalidValue;
     if ((long long)a.Wrows * a.ldw >= (1LL << 31)) return hipErrorInvalidValue;
+    if (a.f8) {
+        switch (vt_conv_gemm_config(a)) {
+            case 9: return launch_cfg_f8<192, 128, 4, 2, true>(a, s);
+            case 2: return launch_cfg_f8<256, 256, 2, 4>(a, s);
+            default: return hipErrorInvalidValue;                          // only the tiles the stride-2 convs use are instantiated
+        }
+    }
     switch (vt_conv_gemm_config(a)) {
         case 0: return launch_cfg<128, 32, 8, 1>(a, s);
         case 1: return launch_cfg<256, 128, 4, 2>(a, s);
@@ -446,6 +499,6 @@ const char* vt_conv_gemm_config_name(int cfg) {
                                                "conv_gemm_kernel<256,256,2,4>", "conv3x3_halo_kernel<2,2,0,8,4>",
                                                "conv3x3_halo_kernel<4,2,0,4,4>", "conv3x3_halo_kernel<4,2,0,8,6>",
                                                "conv3x3_halo_kernel<2,4,0,8,6>", "conv3x3_halo_kernel<.,.,1,8,6>",
-                                               "conv3x3_halo_kernel<.,.,2,8,6>", "conv_gemm_kernel<192,128,4,2,occ2>", "attn_qk_kernel", "conv3x3_halo_fp8_kernel", "attn_pv_kernel", "gn_apply_kernel"};
+                                               "conv3x3_halo_kernel<.,.,2,8,6>", "conv_gemm_kernel<192,128,4,2,occ2>", "attn_qk_kernel", "conv3x3_halo_fp8_kernel", "attn_pv_kernel", "conv_gemm_fp8_kernel", "gn_apply_kernel"};
     return (cfg >= 0 && cfg < VT_NUM_PROF_SLOTS) ? n[cfg] : "?";
 }

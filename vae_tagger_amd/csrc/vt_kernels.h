@@ -38,6 +38,8 @@ struct ConvGemmArgs {
     const int* gate;        // optional: the whole launch is a no-op unless *gate == gate_expect
     int gate_expect;
     int x_stream;           // 1 = X is read once (P of P.V): its LDS-DMA carries the streaming (nt) cache policy
+    int f8;                 // 1 = X and W are e4m3 bytes (ld* / *_bs in elements = bytes); fp8 MFMA, twice the K per K-step
+    const float* col_scale; // optional per-cout multiplier of the accumulator (before the bias)
     int short_tiles;        // 1 = short-K launches and the 128-cout stride-2 conv use the two-workgroups-per-CU tile (vt_set_flag 6)
 };
 int vt_conv_gemm_col_slots(const ConvGemmArgs& a);
@@ -50,8 +52,9 @@ const char* vt_conv_gemm_config_name(int cfg);
 constexpr int VT_PROF_ATTN_QK = 10;
 constexpr int VT_PROF_HALO_FP8 = 11;
 constexpr int VT_PROF_ATTN_PV = 12;
-constexpr int VT_PROF_GN_APPLY = 13;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
-constexpr int VT_NUM_PROF_SLOTS = 14;
+constexpr int VT_PROF_GEMM_FP8 = 13;
+constexpr int VT_PROF_GN_APPLY = 14;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 15;
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
@@ -130,7 +133,8 @@ struct Conv3x3Fp8Args {
     const float* mult;        // [Cout]: weight scale / act_scale
     const float* bias;        // [Cout] or null
     const float* res; const f16_t* res_f16;               // optional residual (at most one)
-    float* out_f32; bf16_t* out_bf16; f16_t* out_f16;     // at least one
+    float* out_f32; bf16_t* out_bf16; f16_t* out_f16;     // at least one of these four
+    unsigned char* out_e4m3; float out_e4m3_scale;        // e4m3(scale * out), saturated: the operand of a following fp8 conv
     const void* zeros;
     float* gn_partial; int gn_cpg;                         // optional [batch][tiles][Cout/gn_cpg][3]
     int batch, H, W, Cin, Cout;
