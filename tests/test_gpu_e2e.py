@@ -327,6 +327,32 @@ def test_config4_fp8_operands_keep_the_logits_within_tolerance(vae, res):
     assert (bf16_logits.cpu() - ref_logits).abs().max().item() <= 1e-3
 
 
+@pytest.mark.parametrize("h,w,b", [(72, 88, 2), (100, 76, 1), (576, 768, 2), (1024, 512, 1)])
+def test_config4_fp8_on_ragged_and_bucket_shapes(vae, h, w, b):
+    """fp8 mode on shapes that are not multiples of its 8 x 32 pixel tile (ragged tiles in every stage, odd sizes into the
+    stride-2 convs) and on two aspect-ratio buckets: logits within 1e-2 of the oracle, and the mode is deterministic."""
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+    n = 1000
+    pipe = EncodeTagPipeline(vae, _decoder(n))
+    x = synth.synth_images(b, h, w, seed=h * 7 + w)
+    sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(n), seed=1)
+    ref_lat = encoder_ref.vae_wrapper_encode(sd_e, x[:1])
+    ref_logits = decoder_ref.attention_decoder_forward(sd_d, ref_lat)
+    try:
+        pipe.ctx.call("vt_set_flag", 11, 1)
+        logits, lat = pipe.logits(x.cuda(), return_latent=True)
+        again = pipe.logits(x.cuda())
+    finally:
+        pipe.ctx.call("vt_set_flag", 11, 0)
+    assert pipe.status() == 0 and torch.equal(again, logits)
+    assert lat.shape == (b, 16, h // 8, w // 8)
+    dg = (logits[:1].cpu() - ref_logits).abs().max().item()
+    dl = (lat[:1].cpu() - ref_lat).abs().max().item()
+    print(f"fp8 {w}x{h}: max|dlatent| {dl:.3e}  max|dlogit| {dg:.3e}")
+    assert dg <= 1e-2 and dl <= 0.25
+
+
 def test_small_config_with_fused_shortcut_on_every_halo_tile_mode():
     """block_out_channels (64, 128): a 128-cout conv2 with the fused 1x1 shortcut (64 -> 128).  Every value of flag 3
     must pick the same tile for the launch and for the GroupNorm-partials bookkeeping (a mismatch reads stale partials)."""
