@@ -78,7 +78,9 @@ __global__ __launch_bounds__(512, 2) void attn_pv_kernel(const AttnPvArgs a) {
     stage(0, 0);
     load_p(0, pf);
     // (splitting the DMA / P-load issue between the two waves of a SIMD, which gained 13 % in attn_qk.hip, cost 10 % here:
-    //  3.76 -> 4.17 ms per step; with two v^T buffers a late-issued tile does not land before the next barrier)
+    //  3.76 -> 4.17 ms per step; with two v^T buffers a late-issued tile does not land before the next barrier.  A ring of four
+    //  32-key stages with counted vmcnt waits and one raw barrier per stage -- the halo kernel's scheme -- ran 3.80 -> 5.33 ms:
+    //  32 MFMAs per barrier are too few for eight waves)
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                               // vmcnt(0) + barrier: tile kt (and pf) landed, buffer (kt+1)&1 free
         if (kt + 1 < nkt) {
