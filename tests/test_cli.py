@@ -19,7 +19,7 @@ def _flags(parser):
 
 def test_cli_flags_match_reference():
     assert REF_FULL_FLAGS <= _flags(infer_full.build_parser())
-    assert _flags(infer_full.build_parser()) - REF_FULL_FLAGS == {"--batch_size", "--device_resize"}
+    assert _flags(infer_full.build_parser()) - REF_FULL_FLAGS == {"--batch_size", "--device_resize", "--fp8"}
     assert _flags(infer_vae.build_parser()) - REF_VAE_FLAGS == {"--batch_size"}
     a = infer_full.build_parser().parse_args(["--vae_checkpoint", "v", "--decoder_checkpoint", "d", "--image_path", "i",
                                               "--tags_csv_path", "t"])
@@ -73,6 +73,15 @@ def test_infer_full_and_infer_vae_end_to_end(tmp_path):
                                str(tmp_path / "tags.csv"), "--output_dir", str(tmp_path / "out_dev"), "--resolution", str(res),
                                "--confidence_threshold", "0.5", "--batch_size", "2", "--device_resize"])
     assert res_dev == res_full
+    # opt-in fp8 mode (BASELINE configs[4]): the same schema; confidences within 1e-2 of the default path's
+    res_f8 = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint",
+                              str(tmp_path / "dec.pth"), "--image_path", str(imgs), "--tags_csv_path",
+                              str(tmp_path / "tags.csv"), "--output_dir", str(tmp_path / "out_f8"), "--resolution", str(res),
+                              "--confidence_threshold", "0.5", "--batch_size", "2", "--fp8"])
+    assert set(res_f8) == set(res_full)
+    for k in res_full:
+        assert abs(res_f8[k]["max_confidence"] - res_full[k]["max_confidence"]) <= 1e-2
+        assert abs(res_f8[k]["avg_confidence_top5"] - res_full[k]["avg_confidence_top5"]) <= 1e-2
     lat = infer_vae.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--image_path", str(imgs),
                           "--output_dir", str(out), "--resolution", str(res)])
     assert len(lat) == 3 and all(len(v) == 16 * (res // 8) ** 2 for v in lat.values())
