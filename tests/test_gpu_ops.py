@@ -249,3 +249,58 @@ def test_fp8_stride2_conv_matches_torch_on_the_same_quantised_operands(ops, B, C
     got = ops.conv3x3_fp8(x, w, b, residual_nchw=res, stride=2)
     assert got.shape == ref.shape
     assert torch.allclose(got, ref + res, rtol=1e-4, atol=2e-3), (got - ref - res).abs().max()
+
+
+def test_c_abi_error_paths_return_codes_and_messages(ops):
+    """The library never aborts: bad arguments, missing weights, short or misaligned workspaces and calls out of order come back
+    as error codes with a message (the reference's per-image try/except relies on failures being catchable)."""
+    import ctypes
+    from vae_tagger_amd import _lib, synth
+    from _util import vp
+    L = _lib.load()
+    ctx = _lib.Context(0)
+    x = torch.zeros(1, 3, 64, 64, device="cuda")
+    lat = torch.zeros(1, 16, 8, 8, device="cuda")
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    # nothing configured yet
+    assert L.vt_encode(ctx.handle, vp(x), 1, 64, 64, 2, vp(lat), vp(ws), ws.numel(), None) == 3          # VT_ERR_STATE
+    assert b"finalized" in L.vt_last_error(ctx.handle)
+    assert L.vt_encoder_finalize(ctx.handle) == 3
+    blocks = (ctypes.c_int * 2)(64, 100)
+    assert L.vt_encoder_configure(ctx.handle, 3, 16, blocks, 2, 2, 32, 1.0, 1, 0.0, 1) == 1               # channels not a multiple of 64
+    blocks = (ctypes.c_int * 2)(64, 64)
+    assert L.vt_encoder_configure(ctx.handle, 4, 16, blocks, 2, 2, 32, 1.0, 1, 0.0, 1) == 1               # in_channels != 3
+    assert L.vt_encoder_configure(ctx.handle, 3, 16, blocks, 2, 1, 32, 1.0, 1, 0.0, 1) == 0
+    assert L.vt_encoder_finalize(ctx.handle) == 4 and b"missing weight" in L.vt_last_error(ctx.handle)     # VT_ERR_MISSING_WEIGHT
+    sd = synth.synth_state_dict(synth.encoder_manifest((64, 64), 3, 16, 1), seed=0)
+    bad = dict(sd); bad["encoder.conv_in.weight"] = torch.zeros(64, 3, 5, 5)
+    for k, v in bad.items():
+        ctx.set_weight(k, v)
+    assert L.vt_encoder_finalize(ctx.handle) == 1 and b"shape mismatch" in L.vt_last_error(ctx.handle)
+    for k, v in sd.items():
+        ctx.set_weight(k, v)
+    assert L.vt_encoder_finalize(ctx.handle) == 0
+    need = L.vt_encode_workspace_bytes(ctx.handle, 1, 64, 64)
+    assert need > 0 and L.vt_encode_workspace_bytes(ctx.handle, 0, 64, 64) == 0 and L.vt_encode_workspace_bytes(ctx.handle, 1, 4, 64) == 0
+    big = torch.zeros(need + 512, dtype=torch.uint8, device="cuda")
+    p = (big.data_ptr() + 255) // 256 * 256
+    assert L.vt_encode(ctx.handle, vp(x), 1, 64, 64, 2, vp(lat), ctypes.c_void_p(p), need - 1, None) == 5    # VT_ERR_WORKSPACE
+    assert L.vt_encode(ctx.handle, vp(x), 1, 64, 64, 2, vp(lat), ctypes.c_void_p(p + 8), need, None) == 1   # misaligned
+    assert L.vt_encode(ctx.handle, None, 1, 64, 64, 2, vp(lat), ctypes.c_void_p(p), need, None) == 1
+    assert L.vt_encode(ctx.handle, vp(x), 1, 64, 64, 7, vp(lat), ctypes.c_void_p(p), need, None) == 1      # bad mode
+    assert L.vt_encode(ctx.handle, vp(x), 1, 64, 64, 2, vp(lat), ctypes.c_void_p(p), need, None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(lat).all() and ctx.status() == 0
+    # decoder: out of order, bad configuration, sort arguments
+    lg = torch.zeros(1, 11, device="cuda")
+    assert L.vt_decode_logits(ctx.handle, vp(lat), 1, 8, 8, vp(lg), vp(ws), ws.numel(), None) == 3
+    assert L.vt_decoder_configure(ctx.handle, 11, 8, 0, 1, 1, 0, 8) == 1                                    # latent_channels != 16
+    assert L.vt_decoder_configure(ctx.handle, 11, 16, 0, 1, 1, 0, 3) == 1                                   # heads must divide 8
+    conf = torch.zeros(1, 11, device="cuda"); idx = torch.zeros(1, 11, dtype=torch.int64, device="cuda")
+    assert L.vt_get_confidence(ctx.handle, vp(lg), 1, 0, vp(conf), vp(idx), None) == 1
+    assert L.vt_get_confidence(ctx.handle, vp(lg), 1, 11, vp(conf), None, None) == 1
+    assert L.vt_set_flag(ctx.handle, 99, 1) == 1 and L.vt_set_flag(ctx.handle, 7, 5) == 1
+    st = ctypes.c_int(7)
+    assert L.vt_status(ctx.handle, 1, None, None) == 1 and L.vt_status(ctx.handle, 1, ctypes.byref(st), None) == 0 and st.value == 0
+    assert L.vt_create(10 ** 6, ctypes.byref(ctypes.c_void_p())) == 2                                        # no such device
+    ctx.close()
