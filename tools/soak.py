@@ -1,5 +1,5 @@
 """Determinism soak of the whole encode+tag step at the bench shape: N repetitions must give bit-identical logits and
-latents (a timing race in an LDS ring shows up as rare differing patches).  python tools/soak.py [reps] [batch]"""
+latents (a timing race in an LDS ring shows up as rare differing patches).  python tools/soak.py [reps] [batch] [flag=value ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,6 +15,9 @@ vae_model = DiffusersVAEWrapper(vae).to("cuda").eval()
 dec = create_attention_decoder(16, 128, 128, 1000, {"use_spatial_attention": True, "use_self_attention": True})
 dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(1000), seed=1), strict=False)
 pipe = EncodeTagPipeline(vae_model, dec.to("cuda").eval())
+for fv in sys.argv[3:]:
+    f, v = fv.split("=")
+    pipe.ctx.call("vt_set_flag", int(f), int(v))
 x = synth.synth_images(B, 1024, 1024, seed=7).cuda()
 ref_logits, ref_lat = pipe.logits(x, return_latent=True)
 ref_logits, ref_lat = ref_logits.clone(), ref_lat.clone()
