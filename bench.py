@@ -196,7 +196,8 @@ def main():
         pipe.ctx.call("vt_set_flag", 3, 0)      # one workgroup per CU for every halo conv
     if a.fp8:
         pipe.ctx.call("vt_set_flag", 11, 1)
-        vae._context().call("vt_set_flag", 11, 1)
+        if a.encode_only:
+            vae._context().call("vt_set_flag", 11, 1)       # (the encode-only leg runs on the VAE mirror's own context)
     for fv in a.flag:
         f, v = fv.split("=")
         pipe.ctx.call("vt_set_flag", int(f), int(v))
