@@ -44,6 +44,16 @@ extern "C" int vt_debug_halo_stamps(unsigned long long* buf) {
 
 namespace {
 
+// HALO_F16 (experiment, tools/bench_halo_power.py): the same instruction stream with v_mfma_f32_16x16x32_f16 on the operand bits
+__device__ __forceinline__ f32x4 halo_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+#ifdef HALO_F16
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
 constexpr int HB = 64;        // bytes per LDS row (32 bf16)
 constexpr int TW = 16;        // tile width in pixels (one MFMA column block)
 constexpr int HWID = TW + 2;  // halo width
@@ -389,7 +399,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 for (int j = 0; j < TP; ++j) {
 #pragma unroll
                     for (int i = 0; i < TC; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[i], xr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = halo_mfma(wfc[i], xr[j], acc[i][j]);
                     if (has_next) {
                         const int rel = (j + dy_n) * HWID + dx_n;
                         xr[j] = *(const bf16x8*)(xs_n + xaddr(rel & 7) + rel * HB);     // its last reader has issued
@@ -428,7 +438,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 for (int j = 0; j < TP; ++j) {
 #pragma unroll
                     for (int i = 0; i < TC; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[i], xr[j + dy], acc[i][j], 0, 0, 0);
+                        acc[i][j] = halo_mfma(wfc[i], xr[j + dy], acc[i][j]);
                     if (next_group) {                                      // rows whose last reader has just issued
                         if (dy == 0 && j == 0) refill(0);
                         if (dy == 1 && j == 0) refill(1);
@@ -485,7 +495,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < TC; ++i)
-                        acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][jh + j], 0, 0, 0);
+                        acc[i][jh + j] = halo_mfma(wf[i], xf[j], acc[i][jh + j]);
             }
             __builtin_amdgcn_s_setprio(0);
             if constexpr (STAGE) {
@@ -551,7 +561,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int i = 0; i < TC; ++i)
-                            acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][jh + j], 0, 0, 0);
+                            acc[i][jh + j] = halo_mfma(wf[i], xf[j], acc[i][jh + j]);
                 }
             }
         }
