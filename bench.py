@@ -310,7 +310,8 @@ def main():
         res = {
             "metric": ("images/sec encode+tag, bucketed 512..1024 bf16" if a.bucketed else
                        "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16").replace(
-                           "bf16", "fp8 (3x3 resnet convs; rest bf16)" if a.fp8 else "bf16"),
+                           "bf16", "fp8 (3x3 resnet convs; rest bf16)" if a.fp8 else "bf16").replace(
+                           "1024^2", "1024^2" if (a.height, a.width) == (1024, 1024) else f"{a.width}x{a.height}"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_step_without_events": round(elapsed_plain / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
