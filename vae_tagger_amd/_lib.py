@@ -7,7 +7,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvae_tagger_hip.so")
+# (VAE_TAGGER_HIP_LIB: an alternative build of the same library, for A/B runs of the test suite)
+LIB_PATH = os.environ.get("VAE_TAGGER_HIP_LIB") or os.path.join(_HERE, "csrc", "libvae_tagger_hip.so")
 
 VT_F32, VT_BF16, VT_F16 = 0, 1, 2
 ENCODE_MOMENTS, ENCODE_MODE, ENCODE_MODE_SCALED = 0, 1, 2
