@@ -359,53 +359,95 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
     }
     if (a.gn_partial) {
         // GroupNorm (n, mean, M2) of this tile's outputs for the next norm.  A group (cpg = 4, 8 or 16 consecutive couts) lives in
-        // one lane; sums are taken relative to a per-(wave, group) pivot, reduced over the wave's 32 pixel columns, then the
+        // one lane; sums are taken relative to a per-(wave half, group) pivot, reduced over the wave's 32 pixel columns, then the
         // two pixel-row waves are merged with Chan's formula in a fixed order (deterministic).
-        __syncthreads();                                   // every wave is done with the staging LDS
-        float* lds = (float*)smem;
+        // This phase is latency, not work (its VALU issue is hidden behind the other resident workgroup's MFMAs, but a 128-channel
+        // layer's main loop is shorter than its epilogue): every group's pivot, sums and lane reductions are independent chains
+        // issued together, cross-lane steps are DPP / readlane (no LDS round trips), one branch writes all partials.
+        float* lds = (float*)(smem + SMEM - WBUF);         // the last weight stage: clear of the residual staging (waves x 16 KB from 0)
+        if (!a.res_f16 && !a.scX) {                        // those paths have passed a barrier since the last K-step's fragment reads
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         const int cpg = a.gn_cpg;
         const int gpb = BC / cpg;
         float npix = 0.f;
 #pragma unroll
         for (int j = 0; j < TP; ++j) npix += (float)__popcll(__ballot((valid >> j) & 1u) & 0xffffffffull);   // lanes 0..31 = the 32 columns
         const float n = npix * (float)cpg;
-        auto stats = [&](auto cpg_tag) {
+        const bool full = __ballot(valid != (1u << TP) - 1u) == 0ull;      // the whole wave tile is inside the image
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        auto stats = [&](auto cpg_tag, auto full_tag) {
             constexpr int CPG = decltype(cpg_tag)::value;
+            constexpr bool FULL = decltype(full_tag)::value;
+            constexpr int NQ = 16 / CPG;
+            float piv[2][NQ], s[2][NQ], ss[2][NQ];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int q = 0; q < 16 / CPG; ++q) {
-                    const float piv = __shfl(acc[h][0][q * CPG], lane & 32, 64);
-                    float s = 0.f, ss = 0.f;
+                for (int q = 0; q < NQ; ++q) {             // pivot = the group's first value at the half-wave's first pixel (finite even outside the image)
+                    const int v = __builtin_bit_cast(int, acc[h][0][q * CPG]);
+                    const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 0));
+                    const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 32));
+                    piv[h][q] = g ? p1 : p0;
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x2 p2 = {piv[h][q], piv[h][q]};
+                    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < TP; ++j) {
-                        if ((valid >> j) & 1u) {
+                        if (FULL || ((valid >> j) & 1u)) {
 #pragma unroll
-                            for (int r = q * CPG; r < (q + 1) * CPG; ++r) { const float d = acc[h][j][r] - piv; s += d; ss = fmaf(d, d, ss); }
+                            for (int r = q * CPG; r < (q + 1) * CPG; r += 2) {
+                                const f32x2 d = f32x2{acc[h][j][r], acc[h][j][r + 1]} - p2;
+                                s2 += d; q2 += d * d;
+                            }
                         }
                     }
-                    s = vt_row16_sum(s); ss = vt_row16_sum(ss);
-                    s += __shfl_xor(s, 16, 64); ss += __shfl_xor(ss, 16, 64);
-                    if (li == 0) {
-                        float mean = 0.f, m2 = 0.f;
-                        if (n > 0.f) { const float ms = s / n; mean = piv + ms; m2 = fmaxf(ss - s * ms, 0.f); }
+                    s[h][q] = s2[0] + s2[1]; ss[h][q] = q2[0] + q2[1];
+                }
+            // 32-column sums: inside each 16-lane row, then row 0 -> row 1 and row 2 -> row 3 (row_bcast15): lanes 16..31 / 48..63 hold them
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float a0 = vt_row16_sum(s[h][q]), b0 = vt_row16_sum(ss[h][q]);
+                    s[h][q] = a0 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x142, 0xA, 0xF, false));
+                    ss[h][q] = b0 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b0), 0x142, 0xA, 0xF, false));
+                }
+            if (li == 16) {
+                const float rn = n > 0.f ? 1.0f / n : 0.f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float ms = s[h][q] * rn;
                         const int lg = (wc * 64 + 32 * h + 16 * g + q * CPG) / CPG;
                         float* d = lds + (wp * gpb + lg) * 3;
-                        d[0] = n; d[1] = mean; d[2] = m2;
+                        d[0] = n; d[1] = n > 0.f ? piv[h][q] + ms : 0.f; d[2] = n > 0.f ? fmaxf(ss[h][q] - s[h][q] * ms, 0.f) : 0.f;
                     }
-                }
             }
         };
-        if (cpg == 4) stats(std::integral_constant<int, 4>{});
-        else if (cpg == 8) stats(std::integral_constant<int, 8>{});
-        else stats(std::integral_constant<int, 16>{});
-        __syncthreads();
+        auto stats_c = [&](auto cpg_tag) {
+            if (full) stats(cpg_tag, std::true_type{}); else stats(cpg_tag, std::false_type{});
+        };
+        if (cpg == 4) stats_c(std::integral_constant<int, 4>{});
+        else if (cpg == 8) stats_c(std::integral_constant<int, 8>{});
+        else stats_c(std::integral_constant<int, 16>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         if ((int)threadIdx.x < gpb) {
+            static_assert(WP == 2, "two pixel-row waves are merged");
+            const float* d0 = lds + threadIdx.x * 3;
+            const float* d1 = lds + (gpb + threadIdx.x) * 3;
             float nn = 0.f, mean = 0.f, m2 = 0.f;
-            for (int w = 0; w < WP; ++w) {
-                const float* d = lds + (w * gpb + threadIdx.x) * 3;
-                vt_chan_merge(nn, mean, m2, d[0], d[1], d[2]);
-            }
+            vt_chan_merge(nn, mean, m2, d0[0], d0[1], d0[2]);
+            vt_chan_merge(nn, mean, m2, d1[0], d1[1], d1[2]);
             const int G = a.Cout / cpg;
             float* o = a.gn_partial + (((long long)b * a.ptiles + tile) * G + c0 / cpg + threadIdx.x) * 3;
             o[0] = nn; o[1] = mean; o[2] = m2;

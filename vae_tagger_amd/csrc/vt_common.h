@@ -14,6 +14,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: launchers call it once per device
 // (bit = current device id; racing first calls at worst set the attribute twice).  `set` performs the hipFuncSetAttribute calls.
 #include <atomic>
+#include <type_traits>
 template <typename F>
 inline hipError_t vt_once_per_device(std::atomic<unsigned long long>& done, F set) {
     int dev = 0;
@@ -160,46 +161,52 @@ __device__ __forceinline__ void vt_gn_epilogue_partials_il(const f32x4 (&v)[TC][
     }
     n *= 4.0f * (float)tpg;
     const bool full = __ballot(valid != (1u << TP) - 1u) == 0ull;       // every pixel of the wave's tile is inside the image
+    // This phase is latency (its VALU issue hides behind the other resident workgroup's MFMAs, but a short main loop does not
+    // cover a long epilogue): all groups' pivots are fetched first, their sums are independent chains, the lane reductions are
+    // DPP, and ONE branch writes every partial.
+    auto partials = [&](auto tpg_tag, auto full_tag) {
+        constexpr int TPG = decltype(tpg_tag)::value;        // tiles per group, compile-time here: no control flow between the chains
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int NG = TC / TPG;
+        float piv[NG], s[NG], ss[NG];
 #pragma unroll
-    for (int g0 = 0; g0 < TC; ++g0) {
-        if (g0 % tpg) continue;                    // g0 = first tile of a group
-        const float piv = __shfl(v[g0][0][0], lane & 48, 64);
-        const f32x2 p2 = {piv, piv};
-        f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};    // two accumulators per sum: packed adds / fmas (v_pk_add_f32, v_pk_fma_f32)
-        if (full) {                                // the common case: no per-row execution masks
+        for (int q = 0; q < NG; ++q) piv[q] = __shfl(v[q * TPG][0][0], lane & 48, 64);
 #pragma unroll
-            for (int i = g0; i < TC; ++i) {
-                if (i >= g0 + tpg) break;
+        for (int q = 0; q < NG; ++q) {
+            const f32x2 p2 = {piv[q], piv[q]};
+            f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};    // two accumulators per sum: packed adds / fmas (v_pk_add_f32, v_pk_fma_f32)
 #pragma unroll
-                for (int j = 0; j < TP; ++j) {
-                    const f32x2 d0 = f32x2{v[i][j][0], v[i][j][1]} - p2, d1 = f32x2{v[i][j][2], v[i][j][3]} - p2;
-                    s2 += d0; q2 += d0 * d0;
-                    s2 += d1; q2 += d1 * d1;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = g0; i < TC; ++i) {
-                if (i >= g0 + tpg) break;
+            for (int i = q * TPG; i < (q + 1) * TPG; ++i) {
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
-                    if ((valid >> j) & 1u) {
+                    if (FULL || ((valid >> j) & 1u)) {
                         const f32x2 d0 = f32x2{v[i][j][0], v[i][j][1]} - p2, d1 = f32x2{v[i][j][2], v[i][j][3]} - p2;
                         s2 += d0; q2 += d0 * d0;
                         s2 += d1; q2 += d1 * d1;
                     }
                 }
             }
+            s[q] = s2[0] + s2[1]; ss[q] = q2[0] + q2[1];
         }
-        const float s = vt_row16_sum(s2[0] + s2[1]), ss = vt_row16_sum(q2[0] + q2[1]);
+#pragma unroll
+        for (int q = 0; q < NG; ++q) { s[q] = vt_row16_sum(s[q]); ss[q] = vt_row16_sum(ss[q]); }
         if (fr == 0) {
-            float mean = 0.f, m2 = 0.f;
-            if (n > 0.f) { const float ms = s / n; mean = piv + ms; m2 = fmaxf(ss - s * ms, 0.f); }
-            const int lg = (wave_cout0 + 16 * fq + 4 * g0) / cpg;
-            float* d = lds + (wp * gpb + lg) * 3;
-            d[0] = n; d[1] = mean; d[2] = m2;
+            const float rn = n > 0.f ? 1.0f / n : 0.f;
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                const float ms = s[q] * rn;
+                const int lg = (wave_cout0 + 16 * fq + 4 * q * TPG) / cpg;
+                float* d = lds + (wp * gpb + lg) * 3;
+                d[0] = n; d[1] = n > 0.f ? piv[q] + ms : 0.f; d[2] = n > 0.f ? fmaxf(ss[q] - s[q] * ms, 0.f) : 0.f;
+            }
         }
-    }
+    };
+    auto partials_f = [&](auto tpg_tag) {
+        if (full) partials(tpg_tag, std::true_type{}); else partials(tpg_tag, std::false_type{});
+    };
+    if (tpg == 1) partials_f(std::integral_constant<int, 1>{});
+    else if (tpg == 2) partials_f(std::integral_constant<int, 2>{});
+    else partials_f(std::integral_constant<int, 4>{});
     __syncthreads();
     if ((int)threadIdx.x < gpb) {
         float nn = 0.f, mean = 0.f, m2 = 0.f;
