@@ -32,8 +32,10 @@ inline hipError_t vt_once_per_device(std::atomic<unsigned long long>& done, F se
 #define VT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 __device__ __forceinline__ float vt_silu(float x) {
-    // x * sigmoid(x); __expf -> v_exp_f32, division -> v_rcp_f32 (error ~1 ulp, far below bf16 output)
-    return x * __frcp_rn(1.0f + __expf(-x));
+    // x * sigmoid(x): v_mul + v_exp_f32, v_add, v_rcp_f32 (1 ulp, far below the bf16 / e4m3 outputs), v_mul.  NOT __frcp_rn: that is
+    // the correctly rounded reciprocal, a ten-instruction v_div_scale / v_div_fmas / v_div_fixup sequence that made the GroupNorm
+    // pass VALU-bound instead of HBM-bound (round 2: 18.6 -> 8.5 VALU instructions per element).
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
 __device__ __forceinline__ float vt_sigmoid_accurate(float x) { return 1.0f / (1.0f + expf(-x)); }
