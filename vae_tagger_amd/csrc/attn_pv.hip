@@ -88,15 +88,22 @@ __global__ __launch_bounds__(512, 2) void attn_pv_kernel(const AttnPvArgs a) {
             load_p(kt + 1, pn);
         }
         const char* vs = smem + (kt & 1) * VBUF;
+        // v^T fragments through a ring of four registers sets, read AHEAD fragments before the MFMAs that use them: left to the
+        // compiler every ds_read_b128 sat directly in front of its two MFMAs behind an s_waitcnt lgkmcnt(0), i.e. one exposed LDS
+        // round trip per 32 matrix-pipe cycles (56 % MFMA busy, 42 % of the wave cycles parked, profiles/r02/mfma_util_*.txt)
+        constexpr int AHEAD = 6;
+        bf16x8 af[8];
+        auto frag = [&](int idx) __attribute__((always_inline)) { return *(const bf16x8*)(vs + (idx & 15) * 16 * ROWB + foff[idx >> 4]); };
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int p = 0; p < AHEAD; ++p) af[p] = frag(p);
 #pragma unroll
-            for (int ct = 0; ct < 16; ++ct) {
-                const bf16x8 af = *(const bf16x8*)(vs + ct * 16 * ROWB + foff[h]);
+        for (int idx = 0; idx < 32; ++idx) {
+            if (idx + AHEAD < 32) af[(idx + AHEAD) & 7] = frag(idx + AHEAD);
+            const int h = idx >> 4, ct = idx & 15;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf[j][h], acc[ct][j], 0, 0, 0);
-            }
+            for (int j = 0; j < 2; ++j)
+                acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[idx & 7], pf[j][h], acc[ct][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);         // keep the read-ahead distance: the scheduler would sink the reads to their uses
         }
         if (kt + 1 < nkt) {
 #pragma unroll

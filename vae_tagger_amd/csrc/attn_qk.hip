@@ -85,8 +85,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     f32x4 acc[4][2];                                    // (every tile's first k-step starts from zero: no clearing)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // P pieces of the previous tile, packed: stored right after the next tile's DMAs are issued, so that the vmcnt(0) in
-    // front of the barrier (one counter for loads and stores on this part) never waits for a store issued just before it
+    // P pieces of a tile, packed by its epilogue and stored right behind it
     // (In the accumulator layout the four pieces of a row's 64-B half line sit in lanes 16 apart, and NEIGHBOURING lanes
     // hold different rows: stored as they stand, every lane's 16 B is its own memory request -- measured, the P write then
     // costs as much as the MFMAs.  The epilogue therefore moves piece (fr, fq) to lane 4 fr + fq with ds_bpermute, so each
@@ -163,43 +162,56 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
         else epilogue_t(kt, std::false_type{});
     };
 
-    // Waves w and w + 4 share a SIMD.  The first four run [MFMAs of tile kt][epilogue of kt] per barrier interval, the other
-    // four [epilogue of kt - 1][MFMAs of kt]: one wave's exp / convert / store work runs beside its partner's MFMAs instead
-    // of both leaving the barrier into the matrix pipe together and into the VALU together.
+    // Waves w and w + 4 share a SIMD.  The first four run [MFMAs of tile kt][DMA of kt + 1][epilogue + stores of kt] per barrier
+    // interval, the other four [DMA of kt + 1][epilogue + stores of kt - 1][MFMAs of kt]: one wave's DMA issue (~100 cycles per
+    // piece), exp / convert / store work runs beside its partner's MFMAs instead of both leaving the barrier into the matrix pipe
+    // together and into the VALU together.
+    // The wait in front of the barrier is COUNTED: vector-memory operations retire in issue order and a wave's P stores (4 per tile
+    // in the fragment order) are always issued after the DMA pieces of the same interval, so s_waitcnt vmcnt(4) covers the key tile
+    // and leaves the stores -- HBM writes -- a second interval to drain (vmcnt(0) parked the wave on them every tile).
     const bool late = (wave & 4) != 0;
     const int nkt = (a.S + KT - 1) / KT;
+    const bool counted = MODE == 3 && row0 < a.S;              // this wave issues exactly 4 stores per epilogue
     stage(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's rows of tile kt have landed ...
+        // stores issued during the previous interval: early waves after every tile, late waves from their second interval on
+        if (counted && kt > (late ? 1 : 0)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows of tile kt have landed ...
         __builtin_amdgcn_s_barrier();                          // ... everyone's; and everyone has READ tile kt - 1
         asm volatile("" ::: "memory");
-        // An LDS-DMA piece costs its wave ~100 issue cycles: the late waves issue theirs now (beside the partner's MFMAs),
-        // the early ones after their MFMAs (beside the partner's) -- not all eight waves at once behind the barrier.
         if (late) {
             if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
             if (kt > 0) { epilogue(kt - 1); if (MODE >= 2) store_held(kt - 1); }
-        } else {
-            if (MODE >= 2 && kt > 0) store_held(kt - 1);       // (a whole interval before the next vmcnt(0))
         }
         const char* ks_base = smem + (kt & 1) * KBUF;
+        // key fragments through a ring of eight register sets, read AHEAD fragments before the two MFMAs that use them: left to the
+        // compiler (246 VGPRs) every ds_read_b128 reused one register set directly in front of its MFMAs behind an
+        // s_waitcnt lgkmcnt(0) -- one exposed LDS round trip per 32 matrix-pipe cycles (51 % MFMA busy, half the wave cycles parked)
+        constexpr int AHEAD = 6;
+        bf16x8 kf[8];
+        auto frag = [&](int idx) __attribute__((always_inline)) {
+            const int ks = idx >> 2, i = idx & 3;
+            return *(const bf16x8*)(ks_base + kbase[ks & 3] + (ks >> 2) * 256 + i * 16 * KROWB);
+        };
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            bf16x8 kf[4];
+        for (int p = 0; p < AHEAD; ++p) kf[p] = frag(p);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kf[i] = *(const bf16x8*)(ks_base + kbase[ks & 3] + (ks >> 2) * 256 + i * 16 * KROWB);
+        for (int idx = 0; idx < 64; ++idx) {
+            if (idx + AHEAD < 64) kf[(idx + AHEAD) & 7] = frag(idx + AHEAD);
+            const int ks = idx >> 2, i = idx & 3;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[j][ks], ks == 0 ? zero4 : acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[idx & 7], qf[j][ks], ks == 0 ? zero4 : acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                 // keep the read-ahead distance: the scheduler would sink the reads to their uses
         }
         if (!late) {
             if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
             epilogue(kt);
+            if (MODE >= 2) store_held(kt);
         }
     }
-    if (nkt > 0) {
-        if (late) epilogue(nkt - 1);
+    if (nkt > 0 && late) {
+        epilogue(nkt - 1);
         if (MODE >= 2) store_held(nkt - 1);
     }
     // ---- the four fq lanes of a row hold its other keys
