@@ -28,6 +28,10 @@ if ROOT not in sys.path:
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (not the 2:1-sparse headline)
 MFMA_FP8_DENSE_PEAK_TFLOPS = 5000.0      # MI355X_MICROARCH.md: ~5 PF dense fp8 (block-scaled f8f6f4 MFMA)
+# what the matrix pipe sustains on THIS chip with operands in registers and random data (tools/mfma_peak.hip,
+# profiles/r02/mfma_peak_bare_loops.log): v_mfma_f32_16x16x32_bf16 2.04-2.09 PF (2.32 on zeros), v_mfma_scale_f32_32x32x64_f8f6f4 4.1 PF (4.96)
+MFMA_BF16_MEASURED_BARE_TFLOPS = 2040.0
+MFMA_FP8_MEASURED_BARE_TFLOPS = 4100.0
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -330,6 +334,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": names[dom].decode(), "achieved": round(achieved, 2),
                          "peak": dom_peak, "unit": "TFLOP/s",
                          "frac": round(achieved / dom_peak, 4),
+                         "peak_measured_bare_mfma_loop": MFMA_FP8_MEASURED_BARE_TFLOPS if dom_peak == MFMA_FP8_DENSE_PEAK_TFLOPS else MFMA_BF16_MEASURED_BARE_TFLOPS,
                          "traffic": None if traffic is None else round(traffic), "traffic_unit": "bytes per launch (mean)",
                          "traffic_source": traffic_src,
                          "launches": int(launches[dom]),
