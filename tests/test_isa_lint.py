@@ -1,0 +1,87 @@
+"""ISA lint (CPU, needs only hipcc): properties of the generated gfx950 code that cost measured time when the compiler lost them.
+
+Round 2 found two by reading the ISA: SiLU compiled to a ten-instruction IEEE division (the GroupNorm pass
+became VALU-bound), and every ds_read_b128 of the attention kernels sat directly in front of its two MFMAs behind an
+s_waitcnt lgkmcnt(0).  These tests cross-compile the three files to assembly and check the hot loops stay as written."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "vae_tagger_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+
+
+def _asm(name, tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-S", "--cuda-device-only",
+           "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(CSRC, name + ".hip")]
+    subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return out.read_text().split("\n")
+
+
+def _functions(lines):
+    """{mangled name: [instruction lines]} for every kernel of the file"""
+    fns, cur = {}, None
+    for l in lines:
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur = m.group(1); fns[cur] = []
+        elif cur is not None:
+            t = l.strip()
+            if t and not t.startswith((";", ".")):
+                fns[cur].append(t)
+            if "s_endpgm" in l:
+                cur = None
+    return fns
+
+
+@pytest.fixture(scope="module")
+def groupnorm_asm(tmp_path_factory):
+    return _functions(_asm("groupnorm", tmp_path_factory))
+
+
+@pytest.fixture(scope="module")
+def attention_asm(tmp_path_factory):
+    return {**_functions(_asm("attn_qk", tmp_path_factory)), **_functions(_asm("attn_pv", tmp_path_factory))}
+
+
+def test_groupnorm_apply_has_no_ieee_division(groupnorm_asm):
+    apply = {k: v for k, v in groupnorm_asm.items() if "gn_apply_kernel" in k}
+    assert len(apply) >= 4
+    for name, ins in apply.items():
+        ops = [i.split()[0] for i in ins]
+        assert not any(o.startswith(("v_div_scale", "v_div_fmas", "v_div_fixup")) for o in ops), name
+        silu = re.search(r"gn_apply_kernelI\w+?Lb(\d)ELb\dE", name).group(1) == "1"          # <T, SILU, OUT8>
+        if silu:                                                       # one v_exp_f32 and one v_rcp_f32 per element
+            assert ops.count("v_exp_f32_e32") == ops.count("v_rcp_f32_e32") > 0, name
+
+
+def _mfma_runs_between_full_lgkm_waits(ins):
+    """lengths of the MFMA runs that an `s_waitcnt lgkmcnt(0)` (alone or combined) separates, inside the part of the kernel that holds MFMAs"""
+    idx = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
+    runs, n = [], 0
+    for l in ins[idx[0]:idx[-1] + 1]:
+        if l.startswith("v_mfma"):
+            n += 1
+        elif l.startswith("s_waitcnt") and "lgkmcnt(0)" in l and n:
+            runs.append(n); n = 0
+    if n:
+        runs.append(n)
+    return runs
+
+
+@pytest.mark.parametrize("kernel", ["attn_qk_kernelILi3E", "attn_pv_kernel"])
+def test_attention_lds_reads_are_ahead_of_their_mfmas(attention_asm, kernel):
+    (name, ins), = [(k, v) for k, v in attention_asm.items() if kernel in k]
+    runs = _mfma_runs_between_full_lgkm_waits(ins)
+    # read-ahead of six fragments: a full LDS drain at most every ~12 MFMAs (it was every 2 when the compiler serialised the reads)
+    assert sum(runs) / len(runs) >= 8.0, (name, runs[:20])
+    # and no drain of the vector-memory counter inside the MFMA stream other than the counted / tile-boundary waits written in the source
+    assert not any(re.search(r"scratch_(load|store)", l) for l in ins[[i for i, l in enumerate(ins) if l.startswith("v_mfma")][0]:
+                                                                      [i for i, l in enumerate(ins) if l.startswith("v_mfma")][-1]]), name
