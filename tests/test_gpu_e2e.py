@@ -390,7 +390,7 @@ def test_device_preprocess_is_bit_exact_with_totensor_normalize(vae):
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("gain,S", [(1.0, 200), (6.0, 200), (1.0, 1024), (6.0, 1024), (6.0, 333), (1.0, 64), (6.0, 64)])   # every GEMM tile config, plain and flagged
+@pytest.mark.parametrize("gain,S", [(1.0, 200), (6.0, 200), (1.0, 1024), (6.0, 1024), (6.0, 333), (1.0, 64), (6.0, 64), (1.0, 2048), (6.0, 2048)])   # every GEMM tile config, plain and flagged; 1024 / 2048: Q.K^T key sweep split over 2 / 4 workgroups
 def test_mid_attention_without_softmax_pass(gain, S):
     """vt_op_attention (E5): the default path has no softmax pass -- Q.K^T emits exp(s - c_i) with c_i from operand norms,
     P.V divides by the row sums.  Every mode stays on the fp32 reference; with to_q / to_k scaled by 6 the norm bound is

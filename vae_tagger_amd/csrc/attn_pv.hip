@@ -119,7 +119,8 @@ __global__ __launch_bounds__(512, 2) void attn_pv_kernel(const AttnPvArgs a) {
     for (int j = 0; j < 2; ++j) {
         const int row = slab * 32 + j * 16 + fr;
         if (row >= a.S) continue;
-        const float rs = a.rinv[(long long)b * a.row_bs + row];
+        const float* ps = a.rsum + (long long)b * a.row_bs + row;       // segment sums of attn_qk, added in a fixed order (its comment)
+        const float rs = 1.f / (((ps[0] + ps[a.split_stride]) + ps[2 * a.split_stride]) + ps[3 * a.split_stride]);
         bf16_t* o = a.o + (long long)b * a.o_bs + (long long)row * a.ldo + cb * CB + 16 * fq;
 #pragma unroll
         for (int G = 0; G < 4; ++G)
@@ -140,9 +141,10 @@ bool vt_attn_pv_supported(int S, int C) { return C == 2 * CB && S > 0; }
 long long vt_attn_pt_elems(int S) { return (long long)((S + 31) / 32) * vt_attn_pt_slab_stride(S); }
 
 hipError_t vt_launch_attn_pv(const AttnPvArgs& a, hipStream_t s) {
-    if (!a.Pt || !a.vt || !a.rinv || !a.o || !a.zeros || a.batch <= 0 || !vt_attn_pv_supported(a.S, a.C)) return hipErrorInvalidValue;
+    if (!a.Pt || !a.vt || !a.rsum || !a.o || !a.zeros || a.batch <= 0 || !vt_attn_pv_supported(a.S, a.C)) return hipErrorInvalidValue;
     if ((a.ldv % 8) || (a.vt_bs % 8) || (a.ldo % 8) || (a.o_bs % 8) || (a.pt_bs % 8) || a.row_bs < a.S) return hipErrorInvalidValue;
     if (a.ldv < (a.S + 7) / 8 * 8 || (long long)a.C * a.ldv >= (1LL << 31)) return hipErrorInvalidValue;
+    if (a.split_stride < (long long)a.batch * a.row_bs) return hipErrorInvalidValue;
     const long long nblk = (long long)((a.S + QB - 1) / QB) * 2 * a.batch;
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> attr_done{0};

@@ -36,8 +36,11 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     const int fr = lane & 15, fq = lane >> 4;
     // an XCD gets a contiguous range of workgroups = the query tiles of one image (or a few): its L2 keeps that image's keys
     const int qtiles = (a.S + QB - 1) / QB;
+    const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
     const int logical = vt_xcd_remap(blockIdx.x, gridDim.x);
-    const int b = logical / qtiles, qt = logical - b * qtiles;
+    const int per_img = qtiles * nsplit;
+    const int b = logical / per_img, qs = logical - b * per_img;
+    const int qt = qs / nsplit, ksp = qs - qt * nsplit;           // the splits of a query block are neighbours: they share its Q rows in L2
     const bf16_t* qb = a.q + (long long)b * a.qk_bs;
     const bf16_t* kb = a.k + (long long)b * a.qk_bs;
     const int row0 = qt * QB + wave * 32;
@@ -157,9 +160,31 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
                 }
         }
     };
+    // MODE 3 (fragment-order P for attn_pv): the row sums leave as FOUR segment sums -- key tiles [i nkt / 4, (i + 1) nkt / 4) -- each
+    // reduced over the row's four lanes and written when its last tile's epilogue has run; attn_pv adds them in the fixed order
+    // ((s0 + s1) + s2) + s3 and inverts.  The association of the additions is then the same whether one workgroup sweeps all keys or
+    // (small grids) 2 or 4 workgroups share a query block's sweep: an image's result does not depend on the batch it ran in, bit for bit.
+    const int nkt_all = (a.S + KT - 1) / KT;
+    const int segb[5] = {0, nkt_all / 4, nkt_all / 2, (int)(3LL * nkt_all / 4), nkt_all};
+    auto write_segment = [&](int seg, bool zero) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v = zero ? 0.f : rv[j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int row = row0 + j * 16 + fr;
+            if (fq == 0 && row < a.S) a.rowout[(long long)seg * a.split_stride + (long long)b * a.row_bs + row] = v;
+            rv[j] = 0.f;
+        }
+    };
     auto epilogue = [&](int kt) __attribute__((always_inline)) {
         if (kt * KT + KT <= a.S) epilogue_t(kt, std::true_type{});
         else epilogue_t(kt, std::false_type{});
+        if (MODE == 3) {
+#pragma unroll
+            for (int seg = 0; seg < 4; ++seg)
+                if (kt + 1 == segb[seg + 1] && segb[seg + 1] > segb[seg]) write_segment(seg, false);
+        }
     };
 
     // Waves w and w + 4 share a SIMD.  The first four run [MFMAs of tile kt][DMA of kt + 1][epilogue + stores of kt] per barrier
@@ -170,18 +195,19 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     // in the fragment order) are always issued after the DMA pieces of the same interval, so s_waitcnt vmcnt(4) covers the key tile
     // and leaves the stores -- HBM writes -- a second interval to drain (vmcnt(0) parked the wave on them every tile).
     const bool late = (wave & 4) != 0;
-    const int nkt = (a.S + KT - 1) / KT;
+    const int seg0 = ksp * (4 / nsplit), seg1 = (ksp + 1) * (4 / nsplit);      // nsplit = 1, 2 or 4: whole segments per workgroup
+    const int kt0 = MODE == 3 ? segb[seg0] : 0, nkt = MODE == 3 ? segb[seg1] : nkt_all;          // this workgroup's key tiles [kt0, nkt)
     const bool counted = MODE == 3 && row0 < a.S;              // this wave issues exactly 4 stores per epilogue
-    stage(0, 0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    stage(kt0, kt0 & 1);
+    for (int kt = kt0; kt < nkt; ++kt) {
         // stores issued during the previous interval: early waves after every tile, late waves from their second interval on
-        if (counted && kt > (late ? 1 : 0)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (counted && kt - kt0 > (late ? 1 : 0)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows of tile kt have landed ...
         __builtin_amdgcn_s_barrier();                          // ... everyone's; and everyone has READ tile kt - 1
         asm volatile("" ::: "memory");
         if (late) {
             if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
-            if (kt > 0) { epilogue(kt - 1); if (MODE >= 2) store_held(kt - 1); }
+            if (kt > kt0) { epilogue(kt - 1); if (MODE >= 2) store_held(kt - 1); }
         }
         const char* ks_base = smem + (kt & 1) * KBUF;
         // key fragments through a ring of eight register sets, read AHEAD fragments before the two MFMAs that use them: left to the
@@ -210,9 +236,16 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
             if (MODE >= 2) store_held(kt);
         }
     }
-    if (nkt > 0 && late) {
+    if (nkt > kt0 && late) {
         epilogue(nkt - 1);
         if (MODE >= 2) store_held(nkt - 1);
+    }
+    if (MODE == 3) {
+        // empty segments (fewer than four key tiles) still have a defined sum
+#pragma unroll
+        for (int seg = 0; seg < 4; ++seg)
+            if (seg >= seg0 && seg < seg1 && segb[seg + 1] == segb[seg]) write_segment(seg, true);
+        return;
     }
     // ---- the four fq lanes of a row hold its other keys
 #pragma unroll
@@ -239,7 +272,9 @@ hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s) {
     if (a.mode == 2 && a.p_frag && a.p_bs < vt_attn_pt_elems(a.S)) return hipErrorInvalidValue;
     if ((a.ldq % 8) || (a.qk_bs % 8) || a.row_bs < a.S) return hipErrorInvalidValue;
     if ((long long)a.S * a.ldq >= (1LL << 31)) return hipErrorInvalidValue;
-    const long long nblk = (long long)((a.S + QB - 1) / QB) * a.batch;
+    if (a.nsplit > 1 && (a.mode != 2 || !a.p_frag || (a.nsplit != 2 && a.nsplit != 4))) return hipErrorInvalidValue;
+    if (a.mode == 2 && a.p_frag && a.split_stride < (long long)a.batch * a.row_bs) return hipErrorInvalidValue;      // rowout = [4 segments][split_stride]
+    const long long nblk = (long long)((a.S + QB - 1) / QB) * a.batch * (a.nsplit > 1 ? a.nsplit : 1);
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> attr_done{0};
     hipError_t ea = vt_once_per_device(attr_done, [&] {

@@ -636,6 +636,15 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
             k.mode = 2; k.P = sc.probs; k.ldp = lp; k.p_bs = (long long)S * lp; k.rowin = shift; k.rowout = rinv; k.gate = nullptr;
             frag_pv = c->attn_pv_kernel && vt_attn_pv_supported(S, C);
             if (frag_pv) { k.p_frag = 1; k.p_bs = vt_attn_pt_elems(S); }
+            if (frag_pv) {
+                // row sums leave as four segment sums in the partials scratch (attn_qk.hip); a small grid (batch 1 at 1024^2: 64 query
+                // blocks on 256 CUs) spreads a query block's segments over 2 or 4 workgroups -- same bits either way
+                if ((size_t)4 * nb * S > sc.group * attn_slots_bound(S) * (size_t)S) return c->fail(VT_ERR_WORKSPACE, "attention: segment sums exceed the scratch");
+                k.rowout = sc.part; k.split_stride = (long long)nb * S;
+                const int qblocks = nb * ((S + 255) / 256), ktiles = (S + 63) / 64;
+                k.nsplit = qblocks > 128 ? 1 : qblocks > 64 ? 2 : 4;
+                while (k.nsplit > 1 && ktiles / k.nsplit < 8) k.nsplit >>= 1;
+            }
             if (c->profiling) {
                 vt_context::ProfRec r;
                 r.e0 = c->next_event(); r.e1 = c->next_event();
@@ -666,7 +675,7 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
         if (frag_pv) {
             AttnPvArgs v{};
             v.Pt = sc.probs; v.pt_bs = vt_attn_pt_elems(S); v.vt = sc.vt + (long long)b0 * C * lp; v.ldv = lp; v.vt_bs = (long long)C * lp;
-            v.rinv = rinv; v.row_bs = S; v.o = sc.o + (long long)b0 * S * C; v.ldo = C; v.o_bs = (long long)S * C;
+            v.rsum = sc.part; v.split_stride = (long long)nb * S; v.row_bs = S; v.o = sc.o + (long long)b0 * S * C; v.ldo = C; v.o_bs = (long long)S * C;
             v.S = S; v.C = C; v.batch = nb; v.zeros = c->zeros;
             if (c->profiling) {
                 vt_context::ProfRec r;

@@ -70,6 +70,10 @@ struct AttnQkArgs {
     int batch;
     const void* zeros;                  // >= 16 zero bytes on the device
     const int* gate; int gate_expect;   // optional: the launch is a no-op unless *gate == gate_expect
+    // fragment-order mode (p_frag): rowout receives FOUR segment sums per row, [4][split_stride] (split_stride >= batch * row_bs) --
+    // key tiles [i n / 4, (i + 1) n / 4) -- which attn_pv adds in a fixed order and inverts; nsplit = 2 or 4 spreads the segments of a
+    // query block over that many workgroups (small grids: batch 1 at 1024^2 has 64 query blocks for 256 CUs) without changing a bit
+    int nsplit; long long split_stride;
 };
 bool vt_attn_qk_supported(int S, int C);
 hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s);
@@ -78,7 +82,8 @@ hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s);
 struct AttnPvArgs {
     const bf16_t* Pt; long long pt_bs;  // fragment-ordered P: [slab of 32 queries][64-key tile][piece j*2+h][lane][8] bf16
     const bf16_t* vt; int ldv; long long vt_bs;   // v^T [C][ldv] bf16 (keys contiguous; keys [S, round8(S)) zero)
-    const float* rinv; long long row_bs;          // 1 / row sum, [batch][row_bs]
+    const float* rsum; long long row_bs;          // attn_qk's four segment sums per row, [4][split_stride] of [batch][row_bs]
+    long long split_stride;
     bf16_t* o; int ldo; long long o_bs;           // [S][ldo] bf16
     int S, C, batch;
     const void* zeros;
