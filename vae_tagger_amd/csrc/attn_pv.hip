@@ -7,7 +7,7 @@
 // LDS, only the v^T tile does (256 channels x 64 keys = 32 KB per key tile, half of what a 256x256 GEMM tile streams per 64 keys),
 // and a wave's 32 x 256 output tile stays in 128 accumulator registers for the whole sweep.
 //   workgroup = 8 waves = 256 query rows x 256 channels (grid: query blocks x 2 channel halves x images; the two halves of a
-//   query block are neighbours in launch order, so the second read of P hits L2); LDS: two v^T tiles (64 KB); 2 workgroups per CU.
+//   query block are neighbours in launch order, so the second read of P hits L2); LDS: two v^T tiles (64 KB); one workgroup per CU (196 VGPRs x 8 waves).
 // Rows of the v^T tile are permuted (interleaved cout map of conv_gemm.hip) so that a lane ends up with 16 consecutive channels.
 #include <hip/hip_runtime.h>
 
@@ -88,9 +88,9 @@ __global__ __launch_bounds__(512, 2) void attn_pv_kernel(const AttnPvArgs a) {
             load_p(kt + 1, pn);
         }
         const char* vs = smem + (kt & 1) * VBUF;
-        // v^T fragments through a ring of four registers sets, read AHEAD fragments before the MFMAs that use them: left to the
+        // v^T fragments through a ring of eight register sets, read AHEAD fragments before the MFMAs that use them: left to the
         // compiler every ds_read_b128 sat directly in front of its two MFMAs behind an s_waitcnt lgkmcnt(0), i.e. one exposed LDS
-        // round trip per 32 matrix-pipe cycles (56 % MFMA busy, 42 % of the wave cycles parked, profiles/r02/mfma_util_*.txt)
+        // round trip per 32 matrix-pipe cycles (56 % MFMA busy, 42 % of the wave cycles parked; now 60 % / 34 %, profiles/r02/mfma_util_*.txt)
         constexpr int AHEAD = 6;
         bf16x8 af[8];
         auto frag = [&](int idx) __attribute__((always_inline)) { return *(const bf16x8*)(vs + (idx & 15) * 16 * ROWB + foff[idx >> 4]); };
