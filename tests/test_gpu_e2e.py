@@ -238,6 +238,7 @@ def test_config2_batch16_1024_matches_oracle_across_attention_groups(vae):
         assert dl <= TOL_LATENT_BF16 and dg <= 1e-2, (i, dl, dg)
     # group-boundary / batch-composition invariance, bit for bit
     assert torch.equal(vae.encode(xd[8:9]), lat[8:9])
+    assert torch.equal(vae.encode(xd[2:4]), lat[2:4])             # 1 / 2 images: Q.K^T splits each query block's key sweep over 4 / 2 workgroups
     assert torch.equal(vae.encode(xd[11:12]), lat[11:12])
     l2, lat2 = pipe.logits(xd[4:13], return_latent=True)     # 9 images: groups of 5 + 4, image 8 now sits in the first group
     assert torch.equal(lat2, lat[4:13]) and torch.equal(l2, logits[4:13])
