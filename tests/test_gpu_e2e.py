@@ -504,8 +504,9 @@ def test_device_resize_is_bit_exact_with_pillow(vae):
         assert torch.equal(pipe.load_image(img, **kw).cpu(), ref_t(img))
 
 
-def test_bench_two_ranks_on_one_gpu_rehearsal(tmp_path):
-    """The N > 1 control flow of bench.py with the HIP path under it: two ranks, both on GPU 0, gloo for the collectives
+@pytest.mark.parametrize("extra", [[], ["--fp8"], ["--bucketed", "--bucket-batch", "2"]], ids=["configs2", "configs4_fp8", "configs3_bucketed"])
+def test_bench_two_ranks_on_one_gpu_rehearsal(tmp_path, extra):
+    """The N > 1 control flow of bench.py with the HIP path under it (default, fp8 and bucketed workloads): two ranks, both on GPU 0, gloo for the collectives
     (VT_BENCH_REHEARSAL=1; RCCL needs one GPU per rank, which this box does not have).  Rank-distinct inputs, one all-gather of
     logits per step, max-over-ranks timing, ONE JSON line from rank 0."""
     import json
@@ -517,11 +518,13 @@ def test_bench_two_ranks_on_one_gpu_rehearsal(tmp_path):
     port = str(29600 + os.getpid() % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
-           "--height", "256", "--width", "256", "--tags", "1000"]
+           "--height", "256", "--width", "256", "--tags", "1000"] + extra
     r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2"
+    assert res["config"]["global_batch"] == (8 if "--bucketed" in extra else 4)        # bucketed: two same-shape batches of 2 per rank and step
+    assert res["dtype"] == ("fp8" if "--fp8" in extra else "bf16")
     assert res["value"] > 0 and res["scaling"] == "weak" and "cpu_baseline" not in res
