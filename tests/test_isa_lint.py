@@ -76,7 +76,7 @@ def _mfma_runs_between_full_lgkm_waits(ins):
     return runs
 
 
-@pytest.mark.parametrize("kernel", ["attn_qk_kernelILi3E", "attn_pv_kernel"])
+@pytest.mark.parametrize("kernel", ["attn_qk_kernelILi3E", "attn_pv_kernelILi256E", "attn_pv_kernelILi128E"])
 def test_attention_lds_reads_are_ahead_of_their_mfmas(attention_asm, kernel):
     (name, ins), = [(k, v) for k, v in attention_asm.items() if kernel in k]
     runs = _mfma_runs_between_full_lgkm_waits(ins)

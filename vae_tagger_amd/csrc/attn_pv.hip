@@ -4,7 +4,7 @@
 // lane (fq, fr) = query row 16 j + fr, keys 32 h + 8 fq .. + 7 -- which is exactly the B operand of v_mfma_f32_16x16x32_bf16 for
 // out^T[c][q] = sum_k v^T[c][k] P[q][k].  So P is stored as it stands (1 KB contiguous per store instruction, no lane permute, a
 // wave's stream over the key tiles sequential in memory) and this kernel loads it straight into registers: P never passes through
-// LDS, only the v^T tile does (256 channels x 64 keys = 32 KB per key tile, half of what a 256x256 GEMM tile streams per 64 keys),
+// LDS, only the v^T tile does (256 channels x 64 keys = 32 KB per key tile, half of what a 256x256 GEMM tile streams per 64 keys; 128 channels on small grids),
 // and a wave's 32 x 256 output tile stays in 128 accumulator registers for the whole sweep.
 //   workgroup = 8 waves = 256 query rows x 256 channels (grid: query blocks x 2 channel halves x images; the two halves of a
 //   query block are neighbours in launch order, so the second read of P hits L2); LDS: two v^T tiles (64 KB); one workgroup per CU (196 VGPRs x 8 waves).
@@ -18,19 +18,24 @@ namespace {
 
 constexpr int QB = 256;        // query rows per workgroup (8 waves x 32)
 constexpr int KT = 64;         // keys per tile
-constexpr int CB = 256;        // channels per workgroup
+constexpr int DCH = 512;       // channels (head dim)
 constexpr int ROWB = KT * 2;   // bytes per LDS row (one channel, 64 keys)
-constexpr int VBUF = CB * ROWB;  // 32 KB
 
+// CB = channels per workgroup: 256 (two workgroups per query block), or 128 for small grids -- batch 1 at 1024^2 has 64 query
+// blocks, i.e. 128 workgroups of the 256-channel form on 256 CUs; four 128-channel workgroups per block fill the chip
+template <int CB>
 __global__ __launch_bounds__(512, 2) void attn_pv_kernel(const AttnPvArgs a) {
+    constexpr int VBUF = CB * ROWB;                    // 32 KB (16 KB)
+    constexpr int NCT = CB / 16;                       // 16-channel MFMA tiles per wave
+    constexpr int NCP = DCH / CB;                      // channel parts per query block
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 v^T tiles
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int qblocks = (a.S + QB - 1) / QB;
     const int logical = vt_xcd_remap(blockIdx.x, gridDim.x);
-    const int cb = logical & 1;                        // channel half: neighbours share the P stream
-    const int rest = logical >> 1;
+    const int cb = logical % NCP;                      // channel part: neighbours share the P stream
+    const int rest = logical / NCP;
     const int b = rest / qblocks, qb = rest - b * qblocks;
     const int nkt = (a.S + KT - 1) / KT;
     const int nslab = (a.S + 31) / 32;
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(512, 2) void attn_pv_kernel(const AttnPvArgs a) {
     const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
     auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < CB / 64; ++jj) {
             const int R = (jj * 8 + wave) * 8 + lrow;
             const int ch = (R & ~63) + (R & 3) + 4 * ((R >> 4) & 3) + 16 * ((R >> 2) & 3);
             const int key = kt * KT + lchunk * 8;
@@ -57,9 +62,9 @@ __global__ __launch_bounds__(512, 2) void attn_pv_kernel(const AttnPvArgs a) {
     // A fragment (channel tile ct, key half h): LDS row ct*16 + fr, logical chunk 4 h + fq -> physical ^ (row & 7) = ^ (fr & 7)
     const int foff[2] = {fr * ROWB + (((0 + fq) ^ (fr & 7)) << 4), fr * ROWB + (((4 + fq) ^ (fr & 7)) << 4)};
 
-    f32x4 acc[16][2];
+    f32x4 acc[NCT][2];
 #pragma unroll
-    for (int ct = 0; ct < 16; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[ct][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -93,13 +98,13 @@ __global__ __launch_bounds__(512, 2) void attn_pv_kernel(const AttnPvArgs a) {
         // round trip per 32 matrix-pipe cycles (56 % MFMA busy, 42 % of the wave cycles parked; now 60 % / 34 %, profiles/r02/mfma_util_*.txt)
         constexpr int AHEAD = 6;
         bf16x8 af[8];
-        auto frag = [&](int idx) __attribute__((always_inline)) { return *(const bf16x8*)(vs + (idx & 15) * 16 * ROWB + foff[idx >> 4]); };
+        auto frag = [&](int idx) __attribute__((always_inline)) { return *(const bf16x8*)(vs + (idx % NCT) * 16 * ROWB + foff[idx / NCT]); };
 #pragma unroll
         for (int p = 0; p < AHEAD; ++p) af[p] = frag(p);
 #pragma unroll
-        for (int idx = 0; idx < 32; ++idx) {
-            if (idx + AHEAD < 32) af[(idx + AHEAD) & 7] = frag(idx + AHEAD);
-            const int h = idx >> 4, ct = idx & 15;
+        for (int idx = 0; idx < 2 * NCT; ++idx) {
+            if (idx + AHEAD < 2 * NCT) af[(idx + AHEAD) & 7] = frag(idx + AHEAD);
+            const int h = idx / NCT, ct = idx % NCT;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[idx & 7], pf[j][h], acc[ct][j], 0, 0, 0);
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void attn_pv_kernel(const AttnPvArgs a) {
         const float rs = 1.f / (((ps[0] + ps[a.split_stride]) + ps[2 * a.split_stride]) + ps[3 * a.split_stride]);
         bf16_t* o = a.o + (long long)b * a.o_bs + (long long)row * a.ldo + cb * CB + 16 * fq;
 #pragma unroll
-        for (int G = 0; G < 4; ++G)
+        for (int G = 0; G < CB / 64; ++G)
 #pragma unroll
             for (int i = 0; i < 4; i += 2) {
                 bf16x8 hv;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void attn_pv_kernel(const AttnPvArgs a) {
 
 }  // namespace
 
-bool vt_attn_pv_supported(int S, int C) { return C == 2 * CB && S > 0; }
+bool vt_attn_pv_supported(int S, int C) { return C == DCH && S > 0; }
 // elements of the fragment-ordered P of one image
 long long vt_attn_pt_elems(int S) { return (long long)((S + 31) / 32) * vt_attn_pt_slab_stride(S); }
 
@@ -145,11 +150,18 @@ hipError_t vt_launch_attn_pv(const AttnPvArgs& a, hipStream_t s) {
     if ((a.ldv % 8) || (a.vt_bs % 8) || (a.ldo % 8) || (a.o_bs % 8) || (a.pt_bs % 8) || a.row_bs < a.S) return hipErrorInvalidValue;
     if (a.ldv < (a.S + 7) / 8 * 8 || (long long)a.C * a.ldv >= (1LL << 31)) return hipErrorInvalidValue;
     if (a.split_stride < (long long)a.batch * a.row_bs) return hipErrorInvalidValue;
-    const long long nblk = (long long)((a.S + QB - 1) / QB) * 2 * a.batch;
+    const long long qblk = (long long)((a.S + QB - 1) / QB) * a.batch;
+    const bool narrow = qblk * 2 < 192;                 // the 256-channel form would leave a quarter or more of the CUs without a workgroup
+    const long long nblk = qblk * (narrow ? 4 : 2);
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> attr_done{0};
-    hipError_t ea = vt_once_per_device(attr_done, [&] { return hipFuncSetAttribute((const void*)attn_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * VBUF); });
+    hipError_t ea = vt_once_per_device(attr_done, [&] {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_pv_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * ROWB);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_pv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * ROWB);
+        return e;
+    });
     if (ea != hipSuccess) return ea;
-    hipLaunchKernelGGL(attn_pv_kernel, dim3((unsigned)nblk), dim3(512), 2 * VBUF, s, a);
+    if (narrow) hipLaunchKernelGGL(attn_pv_kernel<128>, dim3((unsigned)nblk), dim3(512), 2 * 128 * ROWB, s, a);
+    else hipLaunchKernelGGL(attn_pv_kernel<256>, dim3((unsigned)nblk), dim3(512), 2 * 256 * ROWB, s, a);
     return hipGetLastError();
 }
