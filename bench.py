@@ -290,7 +290,8 @@ def main():
     torch.cuda.synchronize()
     elapsed_plain = time.perf_counter() - t1
     status = prof_ctx.status()
-    assert status == 0, f"vt_status = {status}: non-finite activations inside the encoder"
+    assert status == 0, (f"vt_status = {status}: " + ("non-finite activations inside the encoder" if status & 1 else
+                                                       "activations clamped to the e4m3 range (fp8 mode unsuitable for these weights)"))
 
     if rank == 0:
         flops_img = pipe.flops_per_image(a.height, a.width)

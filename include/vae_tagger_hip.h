@@ -68,7 +68,9 @@ int vt_decoder_finalize(vt_context* ctx);
  *                       confidence >= threshold, max confidence, (sum of the first five) / 5, number of non-finite confidences}
  * vt_status          sticky device-side health word of the context (SYNCHRONISES `stream`): bit 0 (VT_STATUS_NONFINITE) =
  *                       some GroupNorm saw non-finite statistics since the last clear -- an activation left the fp16 range
- *                       of the residual-stream storage (rerun with vt_set_flag(ctx, 4, 0)) or the weights hold inf / NaN
+ *                       of the residual-stream storage (rerun with vt_set_flag(ctx, 4, 0)) or the weights hold inf / NaN;
+ *                       bit 1 (VT_STATUS_FP8_SATURATED, fp8 mode only) = some activation exceeded the e4m3 range (+-448 after its
+ *                       scale) and was clamped -- the checkpoint's activations are too large for flag 11; rerun without it
  * vt_encode_tag      <- the loop body of infer_full.py:101-105 for a whole batch
  */
 size_t vt_encode_workspace_bytes(const vt_context* ctx, int B, int H, int W);
@@ -82,7 +84,7 @@ int vt_get_confidence(vt_context* ctx, const float* logits, int B, int N, float*
 int vt_summarize_confidence(vt_context* ctx, const float* conf_sorted, const int64_t* indices, int B, int N, float threshold,
                             int K, float* top_conf_out /* [B][K] */, int32_t* top_idx_out /* [B][K] */,
                             float* stats_out /* [B][4] */, void* stream);
-enum { VT_STATUS_NONFINITE = 1 };
+enum { VT_STATUS_NONFINITE = 1, VT_STATUS_FP8_SATURATED = 2 };
 int vt_status(vt_context* ctx, int clear, int* status_out /* host */, void* stream);
 size_t vt_encode_tag_workspace_bytes(const vt_context* ctx, int B, int H, int W);
 int vt_encode_tag(vt_context* ctx, const float* x_nchw, int B, int H, int W, float* latent_out /* may be NULL */,

@@ -299,6 +299,32 @@ def test_fp16_overflow_trips_the_status_word_and_fp32_storage_matches_oracle():
     assert (lat32.cpu() - ref).abs().max().item() <= TOL_LATENT_BF16
 
 
+def test_fp8_saturation_trips_its_own_status_bit():
+    """fp8 mode clamps to the e4m3 range (+-448 after the activation scale of 8) silently.  With one GroupNorm's affine scaled by 100
+    the normalised activations reach ~+-400: in fp8 mode bit 1 of vt_status (VT_STATUS_FP8_SATURATED) is raised -- sticky, cleared by
+    the read -- and nothing else; on the bf16 path the same weights leave the word at zero."""
+    from vae_tagger_amd._lib import VT_STATUS_FP8_SATURATED
+    from vae_tagger_amd.diffusers_vae_loader import (DiffusersVAEWrapper, get_diffusers_vae_config,
+                                                      load_diffusers_vae_from_config)
+    sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    for k in ("weight", "bias"):
+        sd[f"encoder.down_blocks.0.resnets.0.norm1.{k}"] = sd[f"encoder.down_blocks.0.resnets.0.norm1.{k}"] * 100.0
+    m = load_diffusers_vae_from_config(get_diffusers_vae_config())
+    m.load_state_dict(sd, strict=False)
+    w = DiffusersVAEWrapper(m).to("cuda").eval()
+    x = synth.synth_images(2, 128, 96, seed=5).cuda()
+    ctx = m._context()
+    lat = w.encode(x)
+    assert m.status() == 0 and torch.isfinite(lat).all()
+    try:
+        ctx.call("vt_set_flag", 11, 1)
+        lat8 = w.encode(x)
+        assert m.status() == VT_STATUS_FP8_SATURATED and m.status() == 0
+        assert torch.isfinite(lat8).all()
+    finally:
+        ctx.call("vt_set_flag", 11, 0)
+
+
 @pytest.mark.parametrize("res", [256, 512, 1024])
 def test_config4_fp8_operands_keep_the_logits_within_tolerance(vae, res):
     """BASELINE.json configs[4] (opt-in, vt_set_flag(ctx, 11, 1)): the 20 stride-1 3x3 resnet convs on fp8 e4m3 operands.

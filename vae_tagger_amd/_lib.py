@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VAE_TAGGER_HIP_LIB") or os.path.join(_HERE, "csrc", "libvae_tagger_hip.so")
 
 VT_F32, VT_BF16, VT_F16 = 0, 1, 2
+VT_STATUS_NONFINITE, VT_STATUS_FP8_SATURATED = 1, 2      # bits of vt_status (include/vae_tagger_hip.h)
 ENCODE_MOMENTS, ENCODE_MODE, ENCODE_MODE_SCALED = 0, 1, 2
 
 _c = ctypes
@@ -120,7 +121,8 @@ class Context:
         self.check(getattr(self.lib, name)(self.handle, *args), name)
 
     def status(self, clear=True, stream=None):
-        """Sticky device health word (synchronises the stream): bit 0 = non-finite GroupNorm statistics were seen."""
+        """Sticky device health word (synchronises the stream): bit 0 (VT_STATUS_NONFINITE) = non-finite GroupNorm statistics were
+        seen; bit 1 (VT_STATUS_FP8_SATURATED, fp8 mode) = an activation exceeded the e4m3 range and was clamped."""
         v = _i(0)
         self.call("vt_status", int(clear), ctypes.byref(v), stream if stream is not None else _vp(0))
         return v.value

@@ -405,12 +405,12 @@ int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int
         r.flops = (double)B * HW * n.c * ((xdt == 1 ? 4.0 : 2.0) + (out_fp8 ? 1.0 : 2.0));     // algorithmic bytes: one read + one bf16 / fp8 write
         r.cfg = VT_PROF_GN_APPLY;
         HIPCK(c, hipEventRecord(r.e0, s), "hipEventRecord");
-        HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s, o8), "gn_apply");
+        HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s, o8, c->status), "gn_apply");
         HIPCK(c, hipEventRecord(r.e1, s), "hipEventRecord");
         c->prof.push_back(r);
         return VT_OK;
     }
-    HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s, o8), "gn_apply");
+    HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s, o8, c->status), "gn_apply");
     return VT_OK;
 }
 
@@ -465,7 +465,7 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
         Conv3x3Fp8Args h{};
         h.X = (const unsigned char*)x; h.Wp = w.wp8; h.mult = w.mult8; h.bias = w.b; h.res = res32; h.res_f16 = res16;
         h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16_e4m3 ? nullptr : o16; h.zeros = c->zeros;
-        if (o16_e4m3) { h.out_e4m3 = (unsigned char*)o16; h.out_e4m3_scale = FP8_RES_SCALE; }
+        if (o16_e4m3) { h.out_e4m3 = (unsigned char*)o16; h.out_e4m3_scale = FP8_RES_SCALE; h.status = c->status; }
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
         if (sc) { h.scX = sc->x; h.scW = sc->wp8; h.scCin = sc->cin; h.bias = sc->bias; }
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_fp8_tiles(Hin, Win); }

@@ -283,6 +283,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
         }
     }
     unsigned valid = 0;
+    float amax8 = 0.f;                                  // largest |value| handed to the e4m3 conversion
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int cw = c0 + wc * 64 + 32 * h + 16 * g;
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
                 for (int i = 0; i < 4; ++i) {
                     float t[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_fmed3f(acc[h][j][4 * i + q] * a.out_e4m3_scale, -448.f, 448.f);
+                    for (int q = 0; q < 4; ++q) t[q] = acc[h][j][4 * i + q] * a.out_e4m3_scale;
+                    amax8 = fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fmaxf(fabsf(t[2]), fabsf(t[3])), amax8));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_fmed3f(t[q], -448.f, 448.f);
                     o8[i] = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], o8[i], false);
                     o8[i] = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], o8[i], true);
                 }
@@ -357,6 +361,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
             }
         }
     }
+    if (a.out_e4m3 && a.status && amax8 > 448.f) atomicOr(a.status, 2);      // e4m3 saturates silently: sticky bit 1 of vt_status
     if (a.gn_partial) {
         // GroupNorm (n, mean, M2) of this tile's outputs for the next norm.  A group (cpg = 4, 8 or 16 consecutive couts) lives in
         // one lane; sums are taken relative to a per-(wave half, group) pivot, reduced over the wave's 32 pixel columns, then the

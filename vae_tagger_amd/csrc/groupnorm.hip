@@ -186,7 +186,7 @@ template <typename T, bool SILU, bool OUT8>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x,
                                                               const float* __restrict__ scale_shift,
                                                               void* __restrict__ yv, int HW, int C,
-                                                              int pix_per_block, float out_scale) {
+                                                              int pix_per_block, float out_scale, int* __restrict__ status) {
     constexpr int CPL = 8;
     const int b = blockIdx.y;
     const int tpp = C / CPL, ppp = GN_THREADS / tpp;
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     const int pbeg = blockIdx.x * pix_per_block;
     const int pend = min(HW, pbeg + pix_per_block);
     const long long base = ((long long)b * HW) * C + tc * CPL;
+    float amax = 0.f;                                   // OUT8: largest |scaled activation| this thread converted
 #pragma unroll 4
     for (int p = pbeg + tp; p < pend; p += ppp) {
         float t[CPL];
@@ -217,7 +218,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
         if constexpr (OUT8) {
             int o0 = 0, o1 = 0;
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) t[i] = __builtin_amdgcn_fmed3f(t[i] * out_scale, -448.f, 448.f);
+            for (int i = 0; i < CPL; ++i) t[i] *= out_scale;
+#pragma unroll
+            for (int i = 0; i < CPL; i += 2) amax = fmaxf(fmaxf(fabsf(t[i]), fabsf(t[i + 1])), amax);       // v_max3_f32 with |.| modifiers
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) t[i] = __builtin_amdgcn_fmed3f(t[i], -448.f, 448.f);
             o0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], o0, false);
             o0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], o0, true);
             o1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], o1, false);
@@ -235,6 +240,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
             __builtin_nontemporal_store(o, (bf16x8*)((bf16_t*)yv + base + (long long)p * C));
         }
     }
+    // e4m3 saturates silently: tell the host once if anything was clamped (sticky bit, vt_status); NaN compares false and is the
+    // finalize kernel's business
+    if (OUT8 && status && amax > 448.f) atomicOr(status, 2);
 }
 
 bool gn_shape_ok(int C, int groups) {
@@ -290,7 +298,7 @@ hipError_t vt_launch_gn_finalize(const float* partial, int nparts, int B, int C,
 }
 
 hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shift, void* y, int B, int HW,
-                              int C, int silu, hipStream_t s, float out_fp8_scale) {
+                              int C, int silu, hipStream_t s, float out_fp8_scale, int* status) {
     if (C % 8 || (GN_THREADS % (C / 8)) != 0 || C / 8 > GN_THREADS || B <= 0 || HW <= 0) return hipErrorInvalidValue;
     const bool o8 = out_fp8_scale > 0.f;
     const int ppp = GN_THREADS / (C / 8);
@@ -299,7 +307,7 @@ hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shi
 #endif
     const int ppb = ppp * (out_fp8_scale > 0.f ? 2 * GN_PASSES : GN_PASSES);   // pixels per block: short blocks stream faster (bf16: 5.3 -> 5.9 TB/s at 4 passes; fp8 output: 8 passes +0.6 % images/s)
     dim3 grid((HW + ppb - 1) / ppb, B), block(GN_THREADS);
-#define GN_APPLY(T, A, O) hipLaunchKernelGGL((gn_apply_kernel<T, A, O>), grid, block, 0, s, (const T*)x, scale_shift, y, HW, C, ppb, out_fp8_scale)
+#define GN_APPLY(T, A, O) hipLaunchKernelGGL((gn_apply_kernel<T, A, O>), grid, block, 0, s, (const T*)x, scale_shift, y, HW, C, ppb, out_fp8_scale, status)
 #define GN_APPLY2(T) do { if (silu) { if (o8) GN_APPLY(T, true, true); else GN_APPLY(T, true, false); } \
                           else { if (o8) GN_APPLY(T, false, true); else GN_APPLY(T, false, false); } } while (0)
     if (x_dtype == 1) GN_APPLY2(float);

@@ -140,6 +140,7 @@ struct Conv3x3Fp8Args {
     const float* res; const f16_t* res_f16;               // optional residual (at most one)
     float* out_f32; bf16_t* out_bf16; f16_t* out_f16;     // at least one of these four
     unsigned char* out_e4m3; float out_e4m3_scale;        // e4m3(scale * out), saturated: the operand of a following fp8 conv
+    int* status;                                           // optional device word: bit 1 raised when an e4m3 output was clamped
     const void* zeros;
     float* gn_partial; int gn_cpg;                         // optional [batch][tiles][Cout/gn_cpg][3]
     int batch, H, W, Cin, Cout;
@@ -176,7 +177,8 @@ hipError_t vt_launch_gn_finalize(const float* partial /*[B][nparts][groups][3]*/
 int vt_gn_max_chunks(int HW, int C);
 // y = act(x*scale + shift) -> bf16 rows, or (out_fp8_scale > 0) e4m3 rows of out_fp8_scale * y, saturated at +-448
 hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shift, void* y, int B, int HW,
-                              int C, int silu, hipStream_t s, float out_fp8_scale = 0.f);
+                              int C, int silu, hipStream_t s, float out_fp8_scale = 0.f,
+                              int* status = nullptr /* e4m3 output: bit 1 of this device word is raised if a value was clamped */);
 
 hipError_t vt_launch_preprocess_u8(const unsigned char* in_hwc, float* out_nchw, int B, int H, int W, hipStream_t s);
 // Pillow's two-pass 8-bit resample; tab_*: [n_out][2 + ksize] int32 (first, count, 22-bit coefficients) on the device;

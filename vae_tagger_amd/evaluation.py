@@ -126,9 +126,12 @@ def _check_status(model):
     """After the batch's host copy (a synchronisation point anyway): the encoder's sticky health word (vt_status)."""
     vae = getattr(model, "vae", model)
     ctx = vae._context() if hasattr(vae, "_context") else None
-    if ctx is not None and ctx.status():
+    st = ctx.status() if ctx is not None else 0
+    if st & 1:
         raise FloatingPointError("non-finite activations in the encoder: the fp16 residual-stream storage overflowed "
                                  "(vt_set_flag(ctx, 4, 0) stores it as fp32) or the checkpoint holds inf / NaN")
+    if st & 2:
+        raise FloatingPointError("fp8 mode: activations exceeded the e4m3 range and were clamped (vt_set_flag(ctx, 11, 0) returns to bf16)")
 
 
 def _probabilities(model, decoder, loader, device):

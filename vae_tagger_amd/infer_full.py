@@ -23,6 +23,7 @@ from .diffusers_vae_loader import (DiffusersVAEWrapper, create_vae_from_config_f
                                    load_diffusers_vae_from_config)
 from .modules import (ClassificationDecoder, create_attention_decoder, get_image_paths, get_image_transform,
                       get_vae_latent_info)
+from ._lib import VT_STATUS_FP8_SATURATED, VT_STATUS_NONFINITE
 from .pipeline import EncodeTagPipeline
 
 
@@ -128,7 +129,7 @@ def infer_and_classify(args):
         return
     pipe = EncodeTagPipeline(vae_model, decoder)
     if getattr(args, "fp8", False):
-        pipe.ctx.call("vt_set_flag", 11, 1)
+        pipe.set_fp8(True)
     from PIL import Image
     results, processed, errors = {}, 0, 0
     bs = max(1, int(getattr(args, "batch_size", 8)))
@@ -148,12 +149,19 @@ def infer_and_classify(args):
         try:
             x = torch.stack(batch).to(device)
             conf, idx = pipe.tag(x)
-            if pipe.status():
+            st = pipe.status()
+            if st & VT_STATUS_FP8_SATURATED:
+                # --fp8 and this checkpoint's activations exceed the e4m3 range: the clamped values are not worth tags; bf16 from here on
+                print("警告: 激活值超出fp8(e4m3)范围，改用bf16路径重新计算该批次")
+                pipe.set_fp8(False)
+                conf, idx = pipe.tag(x)
+                st = pipe.status()
+            if st & VT_STATUS_NONFINITE:
                 # an activation left the fp16 range of the residual-stream storage: keep fp32 storage from here on
                 print("警告: 激活值超出fp16范围，改用fp32残差存储重新计算该批次")
                 pipe.set_fp32_residual(True)
                 conf, idx = pipe.tag(x)
-                if pipe.status():
+                if pipe.status() & VT_STATUS_NONFINITE:
                     raise FloatingPointError("non-finite activations even with fp32 residual storage (inf / NaN weights?)")
             for p, entry in zip(names, summarize_batch(pipe, conf, idx, tag_names, args.confidence_threshold)):
                 results[str(p)] = entry

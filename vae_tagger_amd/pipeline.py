@@ -78,9 +78,14 @@ class EncodeTagPipeline:
         return (packed[:, :K].numpy(), packed[:, K:2 * K].contiguous().view(torch.int32).numpy(), packed[:, 2 * K:].numpy())
 
     def status(self, clear=True):
-        """Sticky health word of the context (synchronises): non-zero = non-finite GroupNorm statistics were seen, i.e. an
-        activation left the fp16 range of the residual-stream storage (or the weights hold inf / NaN)."""
+        """Sticky health word of the context (synchronises): bit 0 = non-finite GroupNorm statistics were seen, i.e. an
+        activation left the fp16 range of the residual-stream storage (or the weights hold inf / NaN); bit 1 (fp8 mode) = an
+        activation exceeded the e4m3 range and was clamped -- this checkpoint needs the bf16 path (set_fp8(False))."""
         return self.ctx.status(clear, stream_ptr(self.device))
+
+    def set_fp8(self, on=True):
+        """BASELINE configs[4]: the 3x3 convs of the resnet / downsample stack on fp8 (e4m3) operands (vt_set_flag 11); tagging only."""
+        self.ctx.call("vt_set_flag", 11, 1 if on else 0)
 
     def set_fp32_residual(self, on=True):
         """Store the residual stream as fp32 (and conv1 outputs as bf16) instead of fp16: for checkpoints whose activations
