@@ -82,6 +82,17 @@ def test_infer_full_and_infer_vae_end_to_end(tmp_path):
     for k in res_full:
         assert abs(res_f8[k]["max_confidence"] - res_full[k]["max_confidence"]) <= 1e-2
         assert abs(res_f8[k]["avg_confidence_top5"] - res_full[k]["avg_confidence_top5"]) <= 1e-2
+    # --fp8 on a checkpoint whose activations exceed the e4m3 range: the status word says so and the CLI redoes the batch in bf16,
+    # i.e. writes exactly what the default run of that checkpoint writes
+    sd_big = dict(sd_e)
+    for k in ("weight", "bias"):
+        sd_big[f"encoder.down_blocks.0.resnets.0.norm1.{k}"] = sd_e[f"encoder.down_blocks.0.resnets.0.norm1.{k}"] * 100.0
+    save_file(sd_big, str(tmp_path / "vae_big.safetensors"))
+    common = ["--decoder_checkpoint", str(tmp_path / "dec.pth"), "--image_path", str(imgs), "--tags_csv_path", str(tmp_path / "tags.csv"),
+              "--resolution", str(res), "--confidence_threshold", "0.5", "--batch_size", "2"]
+    big_bf16 = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae_big.safetensors"), "--output_dir", str(tmp_path / "out_b0")] + common)
+    big_fp8 = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae_big.safetensors"), "--output_dir", str(tmp_path / "out_b8"), "--fp8"] + common)
+    assert len(big_bf16) == 3 and big_fp8 == big_bf16
     lat = infer_vae.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--image_path", str(imgs),
                           "--output_dir", str(out), "--resolution", str(res)])
     assert len(lat) == 3 and all(len(v) == 16 * (res // 8) ** 2 for v in lat.values())
