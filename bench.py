@@ -52,6 +52,7 @@ def parse():
                    help="BASELINE configs[4]: the stride-1 3x3 resnet convs on fp8 (e4m3) operands / fp8 MFMA (vt_set_flag 11); opt-in mode, "
                         "logits within 1e-2 of the CPU reference, latents ~1e-1")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-also", action="store_true", help="skip the configs[4] / configs[3] legs attached to the default run's line")
     p.add_argument("--generic-conv", action="store_true", help="A/B: disable the halo-tile 3x3 kernel")
     p.add_argument("--no-occ2", action="store_true", help="A/B: 128-cout convs on the one-workgroup-per-CU tile")
     p.add_argument("--lib", default=None, help="A/B: path of an alternative build of libvae_tagger_hip.so")
@@ -208,96 +209,89 @@ def main():
 
     B = a.batch
     counts = [B] * world
-    images_per_step = world * B
-    flops_step = None
-    if a.bucketed:
-        # reference AspectRatioBucketing(512, 1024, 64) (modules.py:180-222, train_full.sh:13-16): the buckets an
-        # image can actually be assigned to, a seeded draw of 2*world same-shape batches per step, whole batches
-        # placed on ranks by the FLOP cost model (conv ~ pixels, attention ~ pixels^2)
+
+    def make_bucket_plan(n_steps, seed=0):
+        """reference AspectRatioBucketing(512, 1024, 64) (modules.py:180-222, train_full.sh:13-16): the buckets an image can
+        actually be assigned to, a seeded draw of 2*world same-shape batches per step, whole batches placed on ranks by the
+        FLOP cost model (conv ~ pixels, attention ~ pixels^2).  Inputs are made resident in HBM here, before any timing."""
         import random
         from vae_tagger_amd.modules import AspectRatioBucketing
         bk = AspectRatioBucketing(512, 1024, 64)
         reach = sorted({bk.bucket_for_ratio(w / h) for w in range(256, 2049, 8) for h in range(256, 2049, 8)})
-        rng = random.Random(0)
+        rng = random.Random(seed)
         plan = []                                       # per step: [(w, h, n)] and the assignment
-        for _ in range(a.warmup + a.steps):
+        for _ in range(n_steps):
             batches = [(*rng.choice(reach), a.bucket_batch) for _ in range(2 * world)]
             assign, _ = sharding.assign_batches(batches, world)
             plan.append((batches, assign))
-        cache = {}
-
-        def bucket_input(w, h):
-            if (w, h) not in cache:
-                cache[(w, h)] = synth.synth_images(a.bucket_batch, h, w, seed=w * 4096 + h + rank).to(dev)
-            return cache[(w, h)]
-        for batches, assign in plan:                    # inputs resident in HBM before timing
+        for batches, assign in plan:
             for i in assign[rank]:
                 bucket_input(batches[i][0], batches[i][1])
-        images_per_step = 2 * world * a.bucket_batch
-        flops_step = [sum(pipe.flops_per_image(h, w) * n for (w, h, n) in b) for b, _ in plan[a.warmup:]]
-        it = iter(plan)
-    else:
+        return plan
+
+    bucket_cache = {}
+
+    def bucket_input(w, h):
+        if (w, h) not in bucket_cache:
+            bucket_cache[(w, h)] = synth.synth_images(a.bucket_batch, h, w, seed=w * 4096 + h + rank).to(dev)
+        return bucket_cache[(w, h)]
+
+    def bucket_step(batches, assign):
+        outs = [pipe.logits(bucket_input(batches[i][0], batches[i][1])) for i in assign[rank]]
+        local = torch.cat(outs, dim=0) if outs else torch.empty(0, a.tags, device=dev)
+        if world == 1:
+            return local
+        return sharding.all_gather_logits(local, [sum(batches[i][2] for i in assign[r]) for r in range(world)])
+
+    x = None
+    if not a.bucketed:
         # synthetic inputs, resident in HBM before the timed region; distinct per rank (global batch = world*B)
         x = synth.synth_images(B, a.height, a.width, seed=1000 + rank).to(dev)
 
-    def step():
-        if a.bucketed:
-            batches, assign = next(it)
-            outs = [pipe.logits(bucket_input(batches[i][0], batches[i][1])) for i in assign[rank]]
-            local = torch.cat(outs, dim=0) if outs else torch.empty(0, a.tags, device=dev)
-            if world == 1:
-                return local
-            return sharding.all_gather_logits(local, [sum(batches[i][2] for i in assign[r]) for r in range(world)])
+    def plain_step():
         if a.encode_only:
             return vae_model.encode(x)
         logits = pipe.logits(x)
         return sharding.all_gather_logits(logits, counts) if world > 1 else logits
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     prof_ctx = pipe.ctx if not a.encode_only else vae._context()
-    prof_ctx.call("vt_profile_begin")
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    n = prof_ctx.lib.vt_profile_num_configs()
-    launches = (ctypes.c_longlong * n)()
-    tot_ms = (ctypes.c_double * n)()
-    tot_fl = (ctypes.c_double * n)()
-    names = (ctypes.c_char_p * n)()
-    prof_ctx.call("vt_profile_end", n, launches, tot_ms, tot_fl, names)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(out).all()
-    # the same K steps without the per-launch event records (the production path): reported beside the contract number
-    if a.bucketed:
-        it = iter(plan[a.warmup:])
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    elapsed_plain = time.perf_counter() - t1
-    status = prof_ctx.status()
-    assert status == 0, (f"vt_status = {status}: " + ("non-finite activations inside the encoder" if status & 1 else
-                                                       "activations clamped to the e4m3 range (fp8 mode unsuitable for these weights)"))
 
-    if rank == 0:
-        flops_img = pipe.flops_per_image(a.height, a.width)
-        ips = images_per_step * a.steps / elapsed
-        if flops_step is not None:
-            flops_img = sum(flops_step) / (images_per_step * a.steps)      # mean over the drawn buckets
+    def timed(step_fns, profile=True):
+        """EXACTLY len(step_fns) steps bracketed by barrier + synchronize on both sides; MAX over ranks.  With `profile` the
+        library records one hipEvent pair per MFMA / GroupNorm launch on the launch stream (vt_profile_begin/end)."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if profile:
+            prof_ctx.call("vt_profile_begin")
+        t0 = time.perf_counter()
+        out = None
+        for f in step_fns:
+            out = f()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof = None
+        if profile:
+            n = prof_ctx.lib.vt_profile_num_configs()
+            launches = (ctypes.c_longlong * n)()
+            tot_ms = (ctypes.c_double * n)()
+            tot_fl = (ctypes.c_double * n)()
+            names = (ctypes.c_char_p * n)()
+            prof_ctx.call("vt_profile_end", n, launches, tot_ms, tot_fl, names)
+            prof = (n, list(launches), list(tot_ms), list(tot_fl), [nm.decode() for nm in names])
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, out, prof
+
+    def roofline_of(prof, elapsed, traffic_key=None):
+        """`roofline` (dominant MFMA kernel) and `hbm_pass` (GroupNorm apply) objects from one profiled region."""
+        n, launches, tot_ms, tot_fl, names = prof
         nm = n - 1                                   # MFMA kernel slots; the last slot is the HBM-bound GroupNorm pass
         # slots that ran the same kernel (e.g. 128- and 256-cout layers on one halo tile) are one kernel to rocprof too
         first = {}
@@ -308,47 +302,135 @@ def main():
                 launches[i] = 0; tot_ms[i] = 0.0; tot_fl[i] = 0.0
         dom = max(range(nm), key=lambda i: tot_ms[i])
         achieved = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
-        dom_peak = MFMA_FP8_DENSE_PEAK_TFLOPS if b"fp8" in names[dom] else MFMA_BF16_DENSE_PEAK_TFLOPS
+        is8 = "fp8" in names[dom]
+        dom_peak = MFMA_FP8_DENSE_PEAK_TFLOPS if is8 else MFMA_BF16_DENSE_PEAK_TFLOPS
         gemm_ms = sum(tot_ms[i] for i in range(nm))
         gn_gbs = tot_fl[nm] / (tot_ms[nm] * 1e-3) / 1e9 if tot_ms[nm] > 0 else 0.0
-        traffic, traffic_src = (None, None) if (a.bucketed or a.encode_only) else pmc_traffic(names[dom].decode(), B, a.height, a.width, a.fp8)
+        traffic, traffic_src = pmc_traffic(names[dom], *traffic_key) if traffic_key else (None, None)
+        fl8 = sum(tot_fl[i] for i in range(nm) if "fp8" in names[i])          # FLOPs that ran on the fp8 MFMA in this region
+        roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 2), "peak": dom_peak, "unit": "TFLOP/s",
+                "frac": round(achieved / dom_peak, 4),
+                "peak_measured_bare_mfma_loop": MFMA_FP8_MEASURED_BARE_TFLOPS if is8 else MFMA_BF16_MEASURED_BARE_TFLOPS,
+                "traffic": None if traffic is None else round(traffic), "traffic_unit": "bytes per launch (mean)",
+                "traffic_source": traffic_src, "launches": int(launches[dom]),
+                "avg_launch_ms": round(tot_ms[dom] / max(1, launches[dom]), 4),
+                "all_mfma_kernels_share_of_step": round(gemm_ms / (elapsed * 1e3), 4),
+                "per_config": {names[i]: {"launches": int(launches[i]), "ms": round(tot_ms[i], 3),
+                                          "tflops": round(tot_fl[i] / max(tot_ms[i], 1e-9) / 1e9, 2)}
+                               for i in range(nm) if launches[i]}}
+        hbm = {"kernel": names[nm], "bound": "hbm", "achieved": round(gn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(gn_gbs / HBM_PEAK_GBS, 4), "launches": int(launches[nm]),
+               "avg_launch_ms": round(tot_ms[nm] / max(1, launches[nm]), 4),
+               "share_of_step": round(tot_ms[nm] / (elapsed * 1e3), 4)}
+        return roof, hbm, fl8
+
+    def end_to_end(ips_per_gpu, flops_img, fl8_per_image):
+        """End-to-end FLOP/s against the MFMA peak of the operands the FLOPs actually ran on: bf16 mode = the 2.5 PF dense bf16
+        peak; fp8 mode = a FLOP-weighted mixed peak (time at peak = fp8 FLOPs / 5 PF + the rest / 2.5 PF)."""
+        tf = ips_per_gpu * flops_img / 1e12
+        ideal_s = (fl8_per_image / (MFMA_FP8_DENSE_PEAK_TFLOPS * 1e12) + (flops_img - fl8_per_image) / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12))
+        basis = ("2.5 PF dense bf16" if fl8_per_image == 0 else
+                 f"FLOP-weighted mixed peak: {fl8_per_image / flops_img:.3f} of the FLOPs on the fp8 MFMA at 5 PF dense, the rest at 2.5 PF dense bf16")
+        return {"end_to_end_tflops_per_gpu": round(tf, 2), "end_to_end_frac_of_mfma_peak": round(ips_per_gpu * ideal_s, 4),
+                "end_to_end_peak_basis": basis}
+
+    # ---- the headline region --------------------------------------------------------------------------
+    if a.bucketed:
+        plan = make_bucket_plan(a.warmup + a.steps)
+        images_per_step = 2 * world * a.bucket_batch
+        flops_step = [sum(pipe.flops_per_image(h, w) * n for (w, h, n) in b) for b, _ in plan[a.warmup:]]
+        warm = [lambda p=p: bucket_step(*p) for p in plan[:a.warmup]]
+        steps = [lambda p=p: bucket_step(*p) for p in plan[a.warmup:]]
+    else:
+        images_per_step = world * B
+        flops_step = None
+        warm = [plain_step] * a.warmup
+        steps = [plain_step] * a.steps
+    for f in warm:
+        f()
+    elapsed, out, prof = timed(steps)
+    assert torch.isfinite(out).all()
+    # the same K steps without the per-launch event records (the production path): reported beside the contract number
+    elapsed_plain, out, _ = timed(steps, profile=False)
+    status = prof_ctx.status()
+    assert status == 0, (f"vt_status = {status}: " + ("non-finite activations inside the encoder" if status & 1 else
+                                                       "activations clamped to the e4m3 range (fp8 mode unsuitable for these weights)"))
+
+    res = None
+    if rank == 0:
+        flops_img = pipe.flops_per_image(a.height, a.width)
+        ips = images_per_step * a.steps / elapsed
+        if flops_step is not None:
+            flops_img = sum(flops_step) / (images_per_step * a.steps)      # mean over the drawn buckets
+        roof, hbm, fl8 = roofline_of(prof, elapsed, None if (a.bucketed or a.encode_only) else (B, a.height, a.width, a.fp8))
+        cfg = {"workload": (f"configs[3]: bucketed 512->1024 step 64 (67 reachable buckets), {2 * world} same-shape batches of "
+                            f"{a.bucket_batch} per step, FLUX-VAE encode + 8-head attention decoder, {a.tags} tags"
+                            if a.bucketed else
+                            ("configs[4] (per GPU): " if a.fp8 else "configs[2]: " if not a.encode_only else "configs[1]: ")
+                            + f"batch {B}/GPU {a.width}x{a.height} FLUX-VAE encode"
+                            + ("" if a.encode_only else f" + 8-head attention decoder, {a.tags} tags"))
+               + ", random-init weights (seeded), fp32 NCHW input resident in HBM",
+               "global_batch": images_per_step, "parallelism": f"dp{world}", "tflop_per_image": round(flops_img / 1e12, 4)}
+        cfg.update(end_to_end(ips / world, flops_img, fl8 / (images_per_step / world * a.steps)))
         res = {
             "metric": ("images/sec encode+tag, bucketed 512..1024 bf16" if a.bucketed else
                        "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16").replace(
-                           "bf16", "fp8 (3x3 resnet convs; rest bf16)" if a.fp8 else "bf16").replace(
+                           "bf16", "fp8 (3x3 convs; rest bf16)" if a.fp8 else "bf16").replace(
                            "1024^2", "1024^2" if (a.height, a.width) == (1024, 1024) else f"{a.width}x{a.height}"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_step_without_events": round(elapsed_plain / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": (f"configs[3]: bucketed 512->1024 step 64 (67 reachable buckets), {2 * world} same-shape batches of "
-                                    f"{a.bucket_batch} per step, FLUX-VAE encode + 8-head attention decoder, {a.tags} tags"
-                                    if a.bucketed else
-                                    ("configs[4] (per GPU): " if a.fp8 else "configs[2]: " if not a.encode_only else "configs[1]: ")
-                                    + f"batch {B}/GPU {a.width}x{a.height} FLUX-VAE encode"
-                                    + ("" if a.encode_only else f" + 8-head attention decoder, {a.tags} tags"))
-                       + ", random-init weights (seeded), fp32 NCHW input resident in HBM",
-                       "global_batch": images_per_step, "parallelism": f"dp{world}",
-                       "tflop_per_image": round(flops_img / 1e12, 4),
-                       "end_to_end_tflops_per_gpu": round(ips / world * flops_img / 1e12, 2),
-                       "end_to_end_frac_of_mfma_peak": round(ips / world * flops_img / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)},
-            "roofline": {"bound": "mfma", "kernel": names[dom].decode(), "achieved": round(achieved, 2),
-                         "peak": dom_peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / dom_peak, 4),
-                         "peak_measured_bare_mfma_loop": MFMA_FP8_MEASURED_BARE_TFLOPS if dom_peak == MFMA_FP8_DENSE_PEAK_TFLOPS else MFMA_BF16_MEASURED_BARE_TFLOPS,
-                         "traffic": None if traffic is None else round(traffic), "traffic_unit": "bytes per launch (mean)",
-                         "traffic_source": traffic_src,
-                         "launches": int(launches[dom]),
-                         "avg_launch_ms": round(tot_ms[dom] / max(1, launches[dom]), 4),
-                         "all_mfma_kernels_share_of_step": round(gemm_ms / (elapsed * 1e3), 4),
-                         "per_config": {names[i].decode(): {"launches": int(launches[i]), "ms": round(tot_ms[i], 3),
-                                                            "tflops": round(tot_fl[i] / max(tot_ms[i], 1e-9) / 1e9, 2)}
-                                        for i in range(nm) if launches[i]}},
-            "hbm_pass": {"kernel": names[nm].decode(), "bound": "hbm", "achieved": round(gn_gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(gn_gbs / HBM_PEAK_GBS, 4), "launches": int(launches[nm]),
-                         "avg_launch_ms": round(tot_ms[nm] / max(1, launches[nm]), 4),
-                         "share_of_step": round(tot_ms[nm] / (elapsed * 1e3), 4)},
+            "config": cfg, "roofline": roof, "hbm_pass": hbm,
         }
+
+    # ---- the other single-GPU configs of BASELINE.json on the same pipeline, attached to the ONE line as "also" (default run only):
+    # configs[4] per GPU (fp8 mode, same batch) and configs[3] (bucketed batches); ~2 s of GPU time, headline keys untouched
+    default_run = (world == 1 and not (a.fp8 or a.bucketed or a.encode_only or a.generic_conv or a.no_occ2 or a.flag)
+                   and not a.no_also)
+    also_f8_logits = None
+    if default_run:
+        also = {}
+        K2, W2 = 10, 2
+        pipe.ctx.call("vt_set_flag", 11, 1)
+        try:
+            for _ in range(W2):
+                plain_step()
+            e8, out8, prof8 = timed([plain_step] * K2)
+            also_f8_logits = pipe.logits(x[:1])
+            same8 = bool(torch.equal(also_f8_logits[0], out8[0]))
+            st8 = prof_ctx.status()
+        finally:
+            pipe.ctx.call("vt_set_flag", 11, 0)
+        roof8, hbm8, fl8_8 = roofline_of(prof8, e8, (B, a.height, a.width, True))
+        ips8 = B * K2 / e8
+        fimg = pipe.flops_per_image(a.height, a.width)
+        also["configs4_fp8_per_gpu"] = {
+            "workload": f"configs[4] (per GPU): batch {B}/GPU {a.width}x{a.height} encode+tag, {a.tags} tags, 3x3 convs on e4m3 operands (vt_set_flag 11)",
+            "value": round(ips8, 3), "unit": "images/sec", "steps": K2, "warmup": W2, "ms_per_step": round(e8 / K2 * 1e3, 3), "dtype": "fp8",
+            "vt_status": st8, "identical_to_the_batched_result": same8,
+            "roofline": {k: roof8[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms", "traffic", "traffic_source", "per_config")},
+            "hbm_pass": {k: hbm8[k] for k in ("achieved", "frac", "share_of_step")}}
+        also["configs4_fp8_per_gpu"].update(end_to_end(ips8, fimg, fl8_8 / (B * K2)))
+        plan3 = make_bucket_plan(W2 + K2)
+        for p3 in plan3[:W2]:
+            bucket_step(*p3)
+        e3, out3, prof3 = timed([lambda p=p: bucket_step(*p) for p in plan3[W2:]])
+        assert torch.isfinite(out3).all()
+        roof3, hbm3, _ = roofline_of(prof3, e3)
+        n3 = 2 * a.bucket_batch * K2
+        f3 = sum(pipe.flops_per_image(h, w) * n for b3, _ in plan3[W2:] for (w, h, n) in b3) / n3
+        also["configs3_bucketed"] = {
+            "workload": f"configs[3] on one GPU: bucketed 512->1024 step 64, 2 same-shape batches of {a.bucket_batch} per step, {a.tags} tags, bf16",
+            "value": round(n3 / e3, 3), "unit": "images/sec", "steps": K2, "warmup": W2, "ms_per_step": round(e3 / K2 * 1e3, 3), "dtype": "bf16",
+            "tflop_per_image_mean": round(f3 / 1e12, 4),
+            "roofline": {k: roof3[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms")},
+            "hbm_pass": {k: hbm3[k] for k in ("achieved", "frac", "share_of_step")}}
+        also["configs3_bucketed"].update(end_to_end(n3 / e3, f3, 0.0))
+        bucket_cache.clear()
+        res["also"] = also
+
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not a.bucketed:
             # parity half of the metric: image 0 of the measured batch through the HIP path (outside the timed region) against
             # the CPU oracle's warm-up run on the same image
@@ -359,11 +441,26 @@ def main():
                 lg_g, lat_g = pipe.logits(xs, return_latent=True)
             same = torch.equal(lg_g[0], out[0]) if lg_g is not None else torch.equal(lat_g[0], out[0])
             (ref_lat, ref_lg), res["cpu_baseline"] = cpu_baseline(xs.cpu(), a.tags, flops_img)
-            res["max_abs_dlatent"] = float(f"{(lat_g.cpu() - ref_lat).abs().max().item():.3e}")
+            dlat = float(f"{(lat_g.cpu() - ref_lat).abs().max().item():.3e}")
+            res["max_abs_dlatent"] = dlat
+            tol = 1e-2
+            par = {"vs": "oracle/ (CPU fp32 restatement; encoder half unpinned against diffusers, see DESIGN.md section 2)",
+                   "image": "image 0 of the measured batch", "tolerance": tol, "identical_to_the_batched_result": bool(same),
+                   "weights": "PyTorch-init synthetic (parity on a trained checkpoint is unpinned: none is available offline)"}
             if lg_g is not None:
-                res["max_abs_dlogit"] = float(f"{(lg_g.cpu() - ref_lg).abs().max().item():.3e}")
-            res["parity"] = {"vs": "oracle/ (CPU fp32 restatement)", "image": "image 0 of the measured batch",
-                             "tolerance": 1e-2, "identical_to_the_batched_result": bool(same)}
+                dlg = float(f"{(lg_g.cpu() - ref_lg).abs().max().item():.3e}")
+                res["max_abs_dlogit"] = dlg
+                par["logits_within_tolerance"] = bool(dlg <= tol)
+            if a.fp8:
+                par["latents_within_tolerance"] = None
+                par["latents_note"] = "fp8 mode claims the logits only (north_star's fp8 line); its latents (~1e-1) are out of scope, infer_vae stays bf16"
+            else:
+                par["latents_within_tolerance"] = bool(dlat <= tol)
+            res["parity"] = par
+            if also_f8_logits is not None:
+                d8 = float(f"{(also_f8_logits.cpu() - ref_lg).abs().max().item():.3e}")
+                res["also"]["configs4_fp8_per_gpu"]["max_abs_dlogit"] = d8
+                res["also"]["configs4_fp8_per_gpu"]["logits_within_tolerance"] = bool(d8 <= tol)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

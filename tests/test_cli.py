@@ -41,7 +41,7 @@ def test_summarize_matches_reference_schema():
 
 
 @pytest.mark.gpu
-def test_infer_full_and_infer_vae_end_to_end(tmp_path):
+def test_infer_full_and_infer_vae_end_to_end(tmp_path, monkeypatch):
     from PIL import Image
     from safetensors.torch import save_file
     from oracle import decoder_ref, encoder_ref
@@ -73,6 +73,29 @@ def test_infer_full_and_infer_vae_end_to_end(tmp_path):
                                str(tmp_path / "tags.csv"), "--output_dir", str(tmp_path / "out_dev"), "--resolution", str(res),
                                "--confidence_threshold", "0.5", "--batch_size", "2", "--device_resize"])
     assert res_dev == res_full
+    # one image whose tensor holds a NaN (a decode that went wrong) in a batch of three: the device leg fails for the batch, is retried
+    # image by image and loses exactly that ONE image, like the reference's per-image try/except (infer_full.py:130-132); the two
+    # healthy images get the entries of the healthy run (batch composition does not change a bit), and fp16 storage stays on
+    real_tf = infer_full.get_image_transform
+
+    def poisoned(resolution, *a, **kw):
+        tf = real_tf(resolution, *a, **kw)
+
+        def f(img):
+            t = tf(img)
+            if img.size == (90, 160):
+                t[0, 3, 5] = float("nan")
+            return t
+        return f
+    monkeypatch.setattr(infer_full, "get_image_transform", poisoned)
+    res_nan = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint",
+                               str(tmp_path / "dec.pth"), "--image_path", str(imgs), "--tags_csv_path",
+                               str(tmp_path / "tags.csv"), "--output_dir", str(tmp_path / "out_nan"), "--resolution", str(res),
+                               "--confidence_threshold", "0.5", "--batch_size", "4"])
+    monkeypatch.setattr(infer_full, "get_image_transform", real_tf)
+    bad = [k for k in res_full if k.endswith("img2.png")]
+    assert len(bad) == 1 and set(res_nan) == set(res_full) - set(bad)
+    assert all(res_nan[k] == res_full[k] for k in res_nan)
     # opt-in fp8 mode (BASELINE configs[4]): the same schema; confidences within 1e-2 of the default path's
     res_f8 = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint",
                               str(tmp_path / "dec.pth"), "--image_path", str(imgs), "--tags_csv_path",

@@ -13,6 +13,9 @@ pytestmark = pytest.mark.gpu
 
 TOL_LATENT_BF16 = 1e-2      # north_star: latent / logit tensors within 1e-2 for the bf16 path
 TOL_LOGIT_F32 = 1e-3        # decoder runs in fp32: within 1e-3 (observed ~1e-5)
+# fp8 mode (configs[4]) claims the LOGITS (1e-2); its latents are outside north_star's tolerance by design.  These two are regression
+# bounds at what is observed (max 0.10-0.12, rms 0.021 over 256^2 .. 1024^2 and all 16 images of the bench batch), not a parity claim.
+FP8_LATENT_MAX, FP8_LATENT_RMS = 0.13, 0.025
 
 
 @pytest.fixture(scope="module")
@@ -349,7 +352,7 @@ def test_config4_fp8_operands_keep_the_logits_within_tolerance(vae, res):
     dg = (logits.cpu() - ref_logits).abs().max().item()
     print(f"fp8 {res}^2: max|dlatent| {dl.abs().max():.3e} rms {dl.pow(2).mean().sqrt():.3e}  max|dlogit| {dg:.3e}")
     assert dg <= 1e-2
-    assert dl.abs().max().item() <= 0.2 and dl.pow(2).mean().sqrt().item() <= 0.04
+    assert dl.abs().max().item() <= FP8_LATENT_MAX and dl.pow(2).mean().sqrt().item() <= FP8_LATENT_RMS
     bf16_logits = pipe.logits(x.cuda())                       # back on bf16 operands: the tight tolerance again
     assert (bf16_logits.cpu() - ref_logits).abs().max().item() <= 1e-3
 
@@ -377,7 +380,7 @@ def test_config4_fp8_on_ragged_and_bucket_shapes(vae, h, w, b):
     dg = (logits[:1].cpu() - ref_logits).abs().max().item()
     dl = (lat[:1].cpu() - ref_lat).abs().max().item()
     print(f"fp8 {w}x{h}: max|dlatent| {dl:.3e}  max|dlogit| {dg:.3e}")
-    assert dg <= 1e-2 and dl <= 0.25
+    assert dg <= 1e-2 and dl <= FP8_LATENT_MAX
 
 
 def test_small_config_with_fused_shortcut_on_every_halo_tile_mode():
@@ -554,3 +557,64 @@ def test_bench_two_ranks_on_one_gpu_rehearsal(tmp_path, extra):
     assert res["config"]["global_batch"] == (8 if "--bucketed" in extra else 4)        # bucketed: two same-shape batches of 2 per rank and step
     assert res["dtype"] == ("fp8" if "--fp8" in extra else "bf16")
     assert res["value"] > 0 and res["scaling"] == "weak" and "cpu_baseline" not in res
+
+
+def test_rccl_one_rank_communicator_runs_the_logits_all_gather(tmp_path):
+    """RCCL executes on this ROCm build: a child process creates a ONE-rank "nccl" (= RCCL) process group on cuda:0 before any
+    other GPU call, runs the exact collective `bench.py --gpus N` uses -- sharding.all_gather_logits' all_gather_into_tensor
+    branch -- on a [16, 10000] fp32 tensor, and a barrier.  It proves that the library loads, a communicator is created and the
+    collective runs; it says NOTHING about scaling over xGMI (no multi-GPU box is available to this build)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "dev = torch.device('cuda', 0)\n"
+        "dist.init_process_group('nccl', world_size=1, rank=0, device_id=dev)\n"
+        "from vae_tagger_amd import sharding\n"
+        "assert dist.get_backend() == 'nccl'\n"
+        "x = torch.arange(16 * 10000, dtype=torch.float32, device=dev).reshape(16, 10000)\n"
+        "y = sharding.all_gather_logits(x, [16], force_collective=True)\n"
+        "dist.barrier()\n"
+        "torch.cuda.synchronize()\n"
+        "assert y.data_ptr() != x.data_ptr() and torch.equal(y, x)\n"
+        "print('RCCL_OK', torch.cuda.nccl.version())\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29950 + os.getpid() % 40), PYTHONDONTWRITEBYTECODE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"RCCL_OK" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-2000:])
+    print(r.stdout.decode().strip())
+
+
+def test_config4_fp8_batch16_1024_matches_oracle_and_is_batch_invariant(vae):
+    """BASELINE configs[4] at its per-GPU batch: fp8 mode, 16 x 1024^2, 10 000 tags (16-image fp8 halo grids, the mid-block
+    attention as two launch groups).  Images 0 and 11 against the CPU oracle (north_star's fp8 line: logits within 1e-2), and the
+    mode is batch-invariant bit for bit: logits(x[4:13]) == logits(x)[4:13]."""
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+    n = 10000
+    pipe = EncodeTagPipeline(vae, _decoder(n))
+    x = synth.synth_images(16, 1024, 1024, seed=1000)
+    sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(n), seed=1)
+    xg = x.cuda()
+    try:
+        pipe.ctx.call("vt_set_flag", 11, 1)
+        logits, lat = pipe.logits(xg, return_latent=True)
+        part = pipe.logits(xg[4:13])
+    finally:
+        pipe.ctx.call("vt_set_flag", 11, 0)
+    assert pipe.status() == 0
+    assert torch.equal(part, logits[4:13])
+    for i in (0, 11):
+        ref_lat = encoder_ref.vae_wrapper_encode(sd_e, x[i:i + 1])
+        ref_logits = decoder_ref.attention_decoder_forward(sd_d, ref_lat)
+        dl = lat[i:i + 1].cpu() - ref_lat
+        dg = (logits[i:i + 1].cpu() - ref_logits).abs().max().item()
+        print(f"fp8 batch 16, image {i}: max|dlatent| {dl.abs().max():.3e} rms {dl.pow(2).mean().sqrt():.3e}  max|dlogit| {dg:.3e}")
+        assert dg <= 1e-2
+        assert dl.abs().max().item() <= FP8_LATENT_MAX and dl.pow(2).mean().sqrt().item() <= FP8_LATENT_RMS

@@ -291,6 +291,16 @@ def test_c_abi_error_paths_return_codes_and_messages(ops):
     assert L.vt_encode(ctx.handle, vp(x), 1, 64, 64, 2, vp(lat), ctypes.c_void_p(p), need, None) == 0
     torch.cuda.synchronize()
     assert torch.isfinite(lat).all() and ctx.status() == 0
+    # finalize twice without new weights: the first one consumed the host copies and the second frees the packed ones, so the
+    # context must fall back to "not finalized" (no dangling device pointers) until weights are set and finalized again
+    assert L.vt_encoder_finalize(ctx.handle) == 4 and b"missing weight" in L.vt_last_error(ctx.handle)
+    assert L.vt_encode(ctx.handle, vp(x), 1, 64, 64, 2, vp(lat), ctypes.c_void_p(p), need, None) == 3       # VT_ERR_STATE
+    for k, v in sd.items():
+        ctx.set_weight(k, v)
+    assert L.vt_encoder_finalize(ctx.handle) == 0
+    assert L.vt_encode(ctx.handle, vp(x), 1, 64, 64, 2, vp(lat), ctypes.c_void_p(p), need, None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(lat).all()
     # decoder: out of order, bad configuration, sort arguments
     lg = torch.zeros(1, 11, device="cuda")
     assert L.vt_decode_logits(ctx.handle, vp(lat), 1, 8, 8, vp(lg), vp(ws), ws.numel(), None) == 3

@@ -124,7 +124,11 @@ class Context:
         """Sticky device health word (synchronises the stream): bit 0 (VT_STATUS_NONFINITE) = non-finite GroupNorm statistics were
         seen; bit 1 (VT_STATUS_FP8_SATURATED, fp8 mode) = an activation exceeded the e4m3 range and was clamped."""
         v = _i(0)
-        self.call("vt_status", int(clear), ctypes.byref(v), stream if stream is not None else _vp(0))
+        if stream is None:
+            # torch's CURRENT stream of this device, so that the read is ordered after the work it is meant to check
+            import torch
+            stream = _vp(torch.cuda.current_stream(self.device_index).cuda_stream)
+        self.call("vt_status", int(clear), ctypes.byref(v), stream)
         return v.value
 
     def set_weight(self, name, tensor):

@@ -842,6 +842,11 @@ int vt_encoder_finalize(vt_context* c) {
     EncoderW& e = c->enc;
     if (!e.configured) return c->fail(VT_ERR_STATE, "vt_encoder_configure was not called");
     DeviceGuard guard(c);
+    // a second finalize frees the packed weights of the first: until THIS one succeeds the context is "not finalized" and no
+    // weight pointer of the previous packing survives (a failed re-finalize must not leave vt_encode reading freed memory)
+    e.finalized = false;
+    e.conv_in_wpk = nullptr; e.conv_in_w = nullptr; e.conv_in_b = nullptr;
+    e.stages.clear(); e.mid0 = ResnetW(); e.mid1 = ResnetW(); e.attn = AttnW(); e.norm_out = NormW(); e.conv_out = ConvW();
     c->free_allocs(c->enc_allocs);
     c->cur_allocs = &c->enc_allocs;
     int r;
@@ -1099,6 +1104,14 @@ int vt_decoder_finalize(vt_context* c) {
     if (!c) return VT_ERR_INVALID;
     if (!c->dec_configured) return c->fail(VT_ERR_STATE, "vt_decoder_configure was not called");
     DeviceGuard guard(c);
+    c->dec_finalized = false;                      // (see vt_encoder_finalize: a failed re-finalize leaves "not finalized", no dangling pointers)
+    {
+        DecoderWeights fresh;
+        const DecoderWeights& o = c->dec;
+        fresh.num_classes = o.num_classes; fresh.latent_channels = o.latent_channels; fresh.heads = o.heads; fresh.plain = o.plain;
+        fresh.use_spatial = o.use_spatial; fresh.use_self = o.use_self; fresh.use_cross = o.use_cross;
+        c->dec = fresh;
+    }
     c->free_allocs(c->dec_allocs);
     c->cur_allocs = &c->dec_allocs;
     DecoderWeights& d = c->dec;
@@ -1214,9 +1227,11 @@ int vt_status(vt_context* c, int clear, int* status_out, void* stream) {
     if (!status_out) return c->fail(VT_ERR_INVALID, "vt_status: null output");
     hipStream_t s = (hipStream_t)stream;
     int v = 0;
+    // the copy targets a stack slot: nothing may return while it is in flight, so synchronise before looking at any later error
     HIPCK(c, hipMemcpyAsync(&v, c->status, sizeof(int), hipMemcpyDeviceToHost, s), "vt_status copy");
-    if (clear) HIPCK(c, hipMemsetAsync(c->status, 0, sizeof(int), s), "vt_status clear");
+    const hipError_t ec = clear ? hipMemsetAsync(c->status, 0, sizeof(int), s) : hipSuccess;
     HIPCK(c, hipStreamSynchronize(s), "vt_status sync");
+    HIPCK(c, ec, "vt_status clear");
     *status_out = v;
     return VT_OK;
 }

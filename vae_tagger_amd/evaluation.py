@@ -126,7 +126,7 @@ def _check_status(model):
     """After the batch's host copy (a synchronisation point anyway): the encoder's sticky health word (vt_status)."""
     vae = getattr(model, "vae", model)
     ctx = vae._context() if hasattr(vae, "_context") else None
-    st = ctx.status() if ctx is not None else 0
+    st = vae.status() if ctx is not None else 0     # on torch's current stream of the model's device: ordered after the encode
     if st & 1:
         raise FloatingPointError("non-finite activations in the encoder: the fp16 residual-stream storage overflowed "
                                  "(vt_set_flag(ctx, 4, 0) stores it as fp32) or the checkpoint holds inf / NaN")

@@ -133,42 +133,102 @@ def infer_and_classify(args):
     from PIL import Image
     results, processed, errors = {}, 0, 0
     bs = max(1, int(getattr(args, "batch_size", 8)))
+
+    def load(p):
+        img = Image.open(p).convert("RGB")
+        return pipe.load_image(img, resolution=args.resolution) if getattr(args, "device_resize", False) else transform(img)
+
+    def tag_batch(x):
+        """One device batch -> JSON entries.  Both status bits are re-read after every run; a mode switch is permanent."""
+        conf, idx = pipe.tag(x)
+        st = pipe.status()
+        if st & VT_STATUS_FP8_SATURATED:
+            # --fp8 and this checkpoint's activations exceed the e4m3 range: the clamped values are not worth tags; bf16 from here on
+            print("警告: 激活值超出fp8(e4m3)范围，改用bf16路径重新计算该批次")
+            pipe.set_fp8(False)
+            state["fp8"] = False
+            conf, idx = pipe.tag(x)
+            st = pipe.status()
+        if st & VT_STATUS_NONFINITE:
+            # an activation left the fp16 range of the residual-stream storage: keep fp32 storage from here on
+            print("警告: 激活值超出fp16范围，改用fp32残差存储重新计算该批次")
+            pipe.set_fp32_residual(True)
+            conf, idx = pipe.tag(x)
+            st = pipe.status()
+            if st & VT_STATUS_FP8_SATURATED:            # (fp8 still on and only the fp32-storage run clamps)
+                pipe.set_fp8(False)
+                state["fp8"] = False
+                conf, idx = pipe.tag(x)
+                st = pipe.status()
+            if st & VT_STATUS_NONFINITE:
+                pipe.set_fp32_residual(False)           # storage was not the cause: one bad image must not slow the rest of the run
+                raise FloatingPointError("non-finite activations even with fp32 residual storage (inf / NaN pixels or weights?)")
+        return summarize_batch(pipe, conf, idx, tag_names, args.confidence_threshold)
+
+    def clear_status():
+        try:
+            pipe.status(clear=True)                      # the sticky word must not leak into the next healthy batch
+        except Exception:  # noqa: BLE001
+            pass
+
+    def device_leg(tensors, names):
+        """Tag one batch; when the batch fails, retry it image by image so that an error costs ONE image, as in the reference's
+        per-image loop (infer_full.py:130-132).  Returns [(path, entry)] and the number of images lost."""
+        try:
+            return list(zip(names, tag_batch(torch.stack(tensors).to(device)))), 0
+        except Exception as e:  # noqa: BLE001
+            clear_status()
+            if len(names) == 1:
+                print(f"跳过图像 {names[0]}，错误原因: {e}")
+                return [], 1
+        done, lost = [], 0
+        for t, p in zip(tensors, names):
+            try:
+                done.append((p, tag_batch(t[None].to(device))[0]))
+            except Exception as e:  # noqa: BLE001 - skip-and-count (infer_full.py:130-132)
+                clear_status()
+                lost += 1
+                print(f"跳过图像 {p}，错误原因: {e}")
+        return done, lost
+
+    state = {"fp8": bool(getattr(args, "fp8", False))}
+    fp8_done = []                                        # paths whose entries were computed in fp8 mode
     for start in range(0, len(image_paths), bs):
         batch, names = [], []
         for p in image_paths[start:start + bs]:
             try:
-                img = Image.open(p).convert("RGB")
-                batch.append(pipe.load_image(img, resolution=args.resolution) if getattr(args, "device_resize", False)
-                             else transform(img))
+                batch.append(load(p))
                 names.append(p)
             except Exception as e:  # noqa: BLE001 - skip-and-count (infer_full.py:130-132)
                 errors += 1
                 print(f"跳过图像 {p}，错误原因: {e}")
         if not batch:
             continue
-        try:
-            x = torch.stack(batch).to(device)
-            conf, idx = pipe.tag(x)
-            st = pipe.status()
-            if st & VT_STATUS_FP8_SATURATED:
-                # --fp8 and this checkpoint's activations exceed the e4m3 range: the clamped values are not worth tags; bf16 from here on
-                print("警告: 激活值超出fp8(e4m3)范围，改用bf16路径重新计算该批次")
-                pipe.set_fp8(False)
-                conf, idx = pipe.tag(x)
-                st = pipe.status()
-            if st & VT_STATUS_NONFINITE:
-                # an activation left the fp16 range of the residual-stream storage: keep fp32 storage from here on
-                print("警告: 激活值超出fp16范围，改用fp32残差存储重新计算该批次")
-                pipe.set_fp32_residual(True)
-                conf, idx = pipe.tag(x)
-                if pipe.status() & VT_STATUS_NONFINITE:
-                    raise FloatingPointError("non-finite activations even with fp32 residual storage (inf / NaN weights?)")
-            for p, entry in zip(names, summarize_batch(pipe, conf, idx, tag_names, args.confidence_threshold)):
-                results[str(p)] = entry
-                processed += 1
-        except Exception as e:  # noqa: BLE001
-            errors += len(names)
-            print(f"跳过图像 {[str(n) for n in names]}，错误原因: {e}")
+        was_fp8 = state["fp8"]
+        done, lost = device_leg(batch, names)
+        errors += lost
+        for p, entry in done:
+            results[str(p)] = entry
+            processed += 1
+        if was_fp8 and state["fp8"]:
+            fp8_done.extend(p for p, _ in done)
+        elif was_fp8 and fp8_done:
+            # fp8 was abandoned in this batch: ONE output file holds ONE numeric mode -- the earlier fp8 batches are redone in bf16
+            print(f"重新以bf16计算之前的 {len(fp8_done)} 张图像")
+            for s0 in range(0, len(fp8_done), bs):
+                redo = fp8_done[s0:s0 + bs]
+                try:
+                    again, lost = device_leg([load(p) for p in redo], redo)
+                except Exception as e:  # noqa: BLE001
+                    again, lost = [], len(redo)
+                    print(f"跳过图像 {[str(n) for n in redo]}，错误原因: {e}")
+                for p in redo:
+                    results.pop(str(p), None)
+                for p, entry in again:
+                    results[str(p)] = entry
+                processed -= lost
+                errors += lost
+            fp8_done = []
         if (start // bs + 1) % max(1, 100 // bs) == 0:
             print(f"已处理 {processed}/{len(image_paths)} 图像 (跳过 {errors} 个错误)")
     print(f"处理完成！成功: {processed}, 失败: {errors}, 总计: {len(image_paths)}")

@@ -6,8 +6,11 @@ import json
 import os
 from pathlib import Path
 
+import numpy as np
 import torch
 
+from ._lib import VT_STATUS_FP8_SATURATED, VT_STATUS_NONFINITE
+from ._runtime import stream_ptr
 from .diffusers_vae_loader import (DiffusersVAEWrapper, create_vae_from_config_file, get_diffusers_vae_config,
                                    load_diffusers_vae_from_config)
 from .modules import get_image_paths, get_image_transform
@@ -59,13 +62,25 @@ def infer_and_save_latents(args):
             latent = vae_model.encode(x)
             flat = latent.reshape(latent.size(0), -1).cpu().numpy()
             ctx = vae_model.vae._context()
-            if ctx.status():
+            st = ctx.status(stream=stream_ptr(latent.device))
+            if st & VT_STATUS_FP8_SATURATED:
+                # (only when somebody switched this context to fp8 mode: latents are outside that mode's claim)
+                print("警告: 激活值超出fp8(e4m3)范围，改用bf16路径重新计算该批次")
+                ctx.call("vt_set_flag", 11, 0)
+                flat = vae_model.encode(x).reshape(latent.size(0), -1).cpu().numpy()
+                st = ctx.status(stream=stream_ptr(latent.device))
+            if st & VT_STATUS_NONFINITE:
                 # an activation left the fp16 range of the residual-stream storage: keep fp32 storage from here on
                 print("警告: 激活值超出fp16范围，改用fp32残差存储重新计算该批次")
                 ctx.call("vt_set_flag", 4, 0)
                 flat = vae_model.encode(x).reshape(latent.size(0), -1).cpu().numpy()
-                if ctx.status():
-                    raise FloatingPointError("non-finite activations even with fp32 residual storage (inf / NaN weights?)")
+                if ctx.status(stream=stream_ptr(latent.device)) & VT_STATUS_NONFINITE:
+                    ctx.call("vt_set_flag", 4, 1)
+                    raise FloatingPointError("non-finite activations even with fp32 residual storage (inf / NaN pixels or weights?)")
+            # the status word only sees GroupNorm statistics and e4m3 clamps: values that go bad after the last norm (conv_out
+            # weights, the scale / shift stage) are caught on the array that is on the host anyway
+            if not np.isfinite(flat).all():
+                raise FloatingPointError("non-finite latents (inf / NaN in the weights behind the last GroupNorm?)")
             for k, p in enumerate(names):
                 latent_data[str(p)] = flat[k].tolist()
                 processed += 1

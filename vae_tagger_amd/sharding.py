@@ -40,15 +40,17 @@ def assign_batches(batches, world):
     return out, loads
 
 
-def all_gather_logits(local_logits, counts=None, group=None):
+def all_gather_logits(local_logits, counts=None, group=None, force_collective=False):
     """Gather per-rank [n_r, N] logits into [sum n_r, N] in rank order.
 
     Equal counts use one all_gather_into_tensor (a single RCCL all-gather); ragged counts pad to
-    the max and trim.  Works on any backend (gloo on CPU for tests)."""
+    the max and trim.  Works on any backend (gloo on CPU for tests).  A one-rank group returns its
+    input without a collective unless `force_collective` (the RCCL smoke test: the same call on a
+    one-rank communicator)."""
     if not dist.is_available() or not dist.is_initialized():
         return local_logits
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force_collective:
         return local_logits
     n_local, N = local_logits.shape
     if counts is None:
