@@ -38,8 +38,17 @@ extern "C" int vt_debug_halo_stamps(unsigned long long* buf) {
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if (g_halo_stamps && threadIdx.x == STAMP_TID) g_halo_stamps[(long long)blockIdx.x * 16 + (slot)] = t_; \
     } while (0)
+#define STAMP_CLK(slot)                                                                                        \
+    do {                                                                                                       \
+        unsigned long long t_;                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (g_halo_stamps && threadIdx.x == STAMP_TID) g_halo_stamps[(long long)blockIdx.x * 16 + (slot)] = t_; \
+    } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define STAMP_CLK(slot) do {} while (0)
 #endif
 
 namespace {
@@ -352,6 +361,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
         }
     }
     STAMP(2);
+    STAMP_CLK(11);
 
     // One chunk = 9 K-steps (taps).  LAST = the final chunk: no next halo, weight ring drains, so the
     // wait count is computed at run time; every other chunk's counts fold to immediates after unrolling.
@@ -566,6 +576,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             }
         }
     }
+    STAMP_CLK(12);
     STAMP(3);
 #ifdef HALO_STAMP
     asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[TC - 1][TP - 1]));      // the last MFMA results have landed

@@ -20,6 +20,41 @@
 #include "vt_common.h"
 #include "vt_kernels.h"
 
+#ifdef HALO_STAMP
+// Diagnostic build only (tools/stamp_halo_fp8.py): wall-clock stamps (s_memrealtime, 100 MHz) of the phases of one workgroup and
+// one s_memtime (shader clock) pair around the main loop; written only for launches that match the filter, into a buffer nothing
+// else reads.  In the product build no stamp executes.
+__device__ unsigned long long* g_halo8_stamps = nullptr;
+__device__ int g_halo8_filter[3] = {0, 0, 0};         // H, Cin, 1 + (fp16 residual present); 0 = any
+extern "C" int vt_debug_halo_fp8_stamps(unsigned long long* buf, int H, int Cin, int res) {
+    const int f[3] = {H, Cin, res};
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_halo8_filter), f, sizeof(f));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_halo8_stamps), &buf, sizeof(buf));
+}
+#define STAMP_ON (g_halo8_stamps && threadIdx.x == 0 && (!g_halo8_filter[0] || g_halo8_filter[0] == a.H) && \
+                  (!g_halo8_filter[1] || g_halo8_filter[1] == a.Cin) && (!g_halo8_filter[2] || g_halo8_filter[2] == 1 + (a.res_f16 != nullptr)))
+#define STAMP(slot)                                                                                            \
+    do {                                                                                                       \
+        unsigned long long t_;                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (STAMP_ON) g_halo8_stamps[(long long)blockIdx.x * 16 + (slot)] = t_;                                \
+    } while (0)
+#define STAMP_CLK(slot)                                                                                        \
+    do {                                                                                                       \
+        unsigned long long t_;                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (STAMP_ON) g_halo8_stamps[(long long)blockIdx.x * 16 + (slot)] = t_;                                \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#define STAMP_CLK(slot) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int HB = 64;                       // bytes per LDS row
@@ -72,6 +107,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wp = wave / WC, wc = wave % WC;
     const int g = lane >> 5, li = lane & 31;
+    STAMP(0);
 
     // ---- tile coordinates (launch-constant divisors arrive as 2^40 / d + 1 multipliers)
     auto fdiv = [](int n, unsigned long long m, int d) -> int {
@@ -126,6 +162,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
     for (int t = 0; t < LEAD; ++t)
         if (t < nk) issue_w(t);
     asm volatile("" ::: "memory");
+    STAMP(1);
 
     f32x16 acc[2][TP];
 #pragma unroll
@@ -151,6 +188,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
 #pragma unroll
         for (int r = 0; r < TP + 2; ++r) xr[r] = read_frag(xbase, opaque(xrow0) + r * HWID, g);
     }
+    STAMP(2);
+    STAMP_CLK(11);
 
     // One chunk = 9 K-steps (taps, kx-major: step p -> dx = p / 3, dy = p % 3).  VM-op issue order per wave and step:
     // [wait][barrier] ... W(t+LEAD) [+ the next chunk's halo at tap 0], both in the middle of the MFMA sequence.
@@ -208,6 +247,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
     };
     for (int chunk = 0; chunk + 1 < nchunk; ++chunk) do_chunk(chunk, std::false_type{});
     do_chunk(nchunk - 1, std::true_type{});
+    STAMP_CLK(12);
+    STAMP(3);
     if (a.scX) {
         // ---- fused 1x1 shortcut (a resnet block's conv_shortcut): acc += scW . scX at the tile's own pixels, as scCin / 32 plain
         // K-steps of bf16 32x32x16 MFMAs on the SAME accumulators (the fp8 and bf16 32x32 forms share the accumulator layout).
@@ -294,6 +335,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
             bia[i] = a.bias ? *(const f32x4*)(a.bias + cw + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (h == 0 && a.res_f16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's residual tile is in LDS
+#ifdef HALO_STAMP
+        if (h == 0) STAMP(9);
+#endif
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int y = ty0 + wp * TP + j;
@@ -362,6 +406,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
         }
     }
     if (a.out_e4m3 && a.status && amax8 > 448.f) atomicOr(a.status, 2);      // e4m3 saturates silently: sticky bit 1 of vt_status
+    STAMP(4);
     if (a.gn_partial) {
         // GroupNorm (n, mean, M2) of this tile's outputs for the next norm.  A group (cpg = 4, 8 or 16 consecutive couts) lives in
         // one lane; sums are taken relative to a per-(wave half, group) pivot, reduced over the wave's 32 pixel columns, then the
@@ -458,6 +503,17 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
             o[0] = nn; o[1] = mean; o[2] = m2;
         }
     }
+#ifdef HALO_STAMP
+    STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(6);
+    if (STAMP_ON) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_halo8_stamps[(long long)blockIdx.x * 16 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 }  // namespace
