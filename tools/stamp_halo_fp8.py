@@ -67,9 +67,36 @@ def report(tag, nwg, gn, res, per_cu_slots=2):
         ent = t[m, 0].sort().values; end = t[m, 6].sort().values
         if len(ent) > per_cu_slots:
             gaps.append((ent[per_cu_slots:] - end[:-per_cu_slots]).float())
+    # are the two resident workgroups of a CU in phase?  For every workgroup: the share of its main-loop interval [2, 3] during which
+    # the other workgroup(s) on the same CU are inside THEIR main loops (1 = lockstep: both loops share the matrix pipe and both sets of
+    # tile ends are exposed; 0 = alternating: one workgroup's ends run under the other's loop)
+    import numpy as np
+    k_np = key.numpy(); a2 = t[:, 2].numpy().astype(np.float64); a3 = t[:, 3].numpy().astype(np.float64)
+    share, first = [], []
+    for k in np.unique(k_np):
+        m = np.nonzero(k_np == k)[0]
+        o = m[np.argsort(a2[m])]
+        for ii, w in enumerate(o):
+            ov = 0.0
+            for v in o[max(0, ii - 3):ii + 4]:
+                if v != w:
+                    ov += max(0.0, min(a3[w], a3[v]) - max(a2[w], a2[v]))
+            share.append(ov / max(a3[w] - a2[w], 1.0))
+        if len(o) >= 2:
+            first.append((a2[o[1]] - a2[o[0]]) / 100.0)
+    share = np.array(share)
+    print(f"   share of a main loop spent beside the co-resident workgroup's main loop: median {np.median(share):.2f}  p10 {np.quantile(share, 0.1):.2f}  p90 {np.quantile(share, 0.9):.2f}"
+          f"   (first two workgroups of a CU start their loops {np.median(first):.2f} us apart)")
     if gaps:
         g = torch.cat(gaps)
         print(f"   CUs seen {len(key.unique())}; next workgroup's entry minus the end of the one it replaces: median {g.median().item() / 100:.2f} us  p10 {g.quantile(0.1).item() / 100:.2f}  p90 {g.quantile(0.9).item() / 100:.2f}", flush=True)
+
+
+def dispatch_map(tag):
+    """which CU do the first workgroups of a grid land on? (xcc, cu) of blocks 0..7, 8..15, 256..263, 512..519"""
+    s = st.cpu()
+    cu = lambda i: ((s[i, 7] >> 32).item(), ((s[i, 7] & 0xffffffff) >> 8 & 0xff).item())
+    print(f"{tag}: dispatch map (xcc, cu) " + "; ".join(f"b{i}:{cu(i)}" for i in (0, 1, 8, 16, 24, 256, 264, 512, 520, 2048, 2056)))
 
 
 pipe.set_fp8(True)
@@ -85,6 +112,8 @@ for tag, H, Cin, res, nwg, gn in (("fp8 128->128 @1024^2 conv1 (no residual)", 1
     pipe.logits(x); torch.cuda.synchronize()
     assert L.vt_debug_halo_fp8_stamps(None, 0, 0, 0) == 0
     report(tag, nwg, gn, res == 2)
+    if H == 1024 and res == 2:
+        dispatch_map(tag)
 pipe.set_fp8(False)
 for _ in range(3):
     pipe.logits(x)
