@@ -34,6 +34,10 @@ CONV_CASES = [
     (2, 256, 256, 33, 17, 3, 1, 1, 1),      # halo kernel <2,4>: ragged 16x16 tiles
     (1, 512, 512, 16, 16, 3, 1, 1, 1),      # 16 channel chunks, two cout tiles
     (1, 32, 128, 9, 9, 3, 1, 1, 1),         # single channel chunk (last-chunk path only)
+    (1, 256, 256, 70, 39, 3, 2, 0, 1),      # stride-2 phase-plane kernel: 3 x 2 tiles of 16 x 16 outputs, ragged both ways, 8 chunks, 2 cout tiles
+    (2, 128, 128, 64, 64, 3, 2, 0, 1),      # even sizes: the (0,1,0,1) padding row / column is read
+    (1, 512, 512, 33, 34, 3, 2, 0, 1),      # 16 chunks (plane ring wraps 21 times), 4 cout tiles, one tile + one row
+    (1, 32, 128, 6, 6, 3, 2, 0, 1),         # single channel chunk
 ]
 
 
@@ -59,6 +63,24 @@ def test_conv2d_matches_torch(ops, conv_kernel, B, Cin, Cout, H, W, k, stride, p
     assert torch.allclose(got16, bf16_round(ref), rtol=1e-2, atol=1e-2)
     got = ops.conv2d(x, w, None, stride=stride, pad_lo=plo, pad_hi=phi)
     assert torch.allclose(got, ref - res - b.view(1, -1, 1, 1), rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("s2_halo", [1, 0], ids=["phase_plane", "generic"])
+def test_conv2d_stride2_identity_taps(ops, s2_halo):
+    """Downsample2D's conv (pad (0,1,0,1), stride 2) with one-hot weights, one tap at a time, on an asymmetric input: every tap must read
+    in(2y + ky, 2x + kx) exactly (a swapped plane, shift or weight step shows as a wrong pixel, not as a tolerance)."""
+    Cin = Cout = 128
+    x = torch.arange(2 * Cin * 21 * 38, dtype=torch.float32).reshape(2, Cin, 21, 38) % 251 - 125.0
+    ops.ctx.call("vt_set_flag", 13, s2_halo)
+    try:
+        for tap in range(9):
+            w = torch.zeros(Cout, Cin, 3, 3)
+            w[torch.arange(Cout), torch.arange(Cin), tap // 3, tap % 3] = 1.0
+            ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, stride=2)
+            got = ops.conv2d(x, w, None, stride=2, pad_lo=0, pad_hi=1)
+            assert got.shape == ref.shape and torch.equal(got, ref), f"tap {tap}"
+    finally:
+        ops.ctx.call("vt_set_flag", 13, 1)
 
 
 def test_conv2d_identity_weights_asymmetric_input(ops, conv_kernel):

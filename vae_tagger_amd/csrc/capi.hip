@@ -24,6 +24,7 @@ struct HostTensor {
 
 struct ConvW {
     const bf16_t* w = nullptr; const bf16_t* wp = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0;   // w: [cout][tap][cin]; wp: halo-kernel packing
+    const bf16_t* wp2 = nullptr;        // stride-2 phase-plane kernel's packing (conv3x3_s2_halo.hip)
     const unsigned char* wp8 = nullptr; const float* mult8 = nullptr;   // fp8 halo kernel: e4m3 weights / per-cout (scale / act_scale)
     const unsigned char* w8g = nullptr; const float* mult8g = nullptr;  // fp8 generic GEMM (stride-2 convs): [cout][tap][cin] e4m3 / per-cout scale (input scale 1)
 };
@@ -134,6 +135,7 @@ struct vt_context {
     int fp8 = 0;                    // vt_set_flag(ctx, 11, v): stride-1 3x3 resnet convs on fp8 (e4m3) operands (BASELINE configs[4])
     int halo_occ2 = 3;              // vt_set_flag(ctx, 3, v): two-workgroups-per-CU tile mode of the halo conv
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
+    int s2_halo = 1;                // vt_set_flag(ctx, 13, v): stride-2 convs on the phase-plane halo kernel instead of the generic GEMM
     // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
     int* rs_host = nullptr; size_t rs_host_ints = 0; hipEvent_t rs_event = nullptr;
     int conv_in_mfma = 1;           // vt_set_flag(ctx, 5, v): conv_in on the matrix cores (bf16 im2col), else exact fp32 VALU
@@ -194,7 +196,7 @@ struct DeviceGuard {
 #define HIPCK(ctx, e, what) do { hipError_t _e = (e); if (_e != hipSuccess) return (ctx)->hipfail(_e, what); } while (0)
 
 // ---- weight packing -------------------------------------------------------------------------------
-int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, ConvW* out) {
+int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, ConvW* out, bool stride2 = false) {
     const HostTensor* w = c->find(name + ".weight");
     const HostTensor* b = c->find(name + ".bias");
     if (!w || !b) return c->fail(VT_ERR_MISSING_WEIGHT, "missing weight %s.{weight,bias}", name.c_str());
@@ -219,6 +221,16 @@ int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, C
                     hp[(((size_t)(i >> 5) * 9 + vt_halo_step_of_tap(t)) * cout + ((o & ~63) + vt_halo_row_of_cout(o & 63))) * 32 + (i & 31)] = p[((size_t)o * 9 + t) * cin + i];
         out->wp = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
         if (!out->wp) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+    }
+    if (k == 3 && stride2 && vt_conv3x3_s2_supported(cin, cout)) {
+        // stride-2 kernel: Wp2[cin/32][step][cout row][32], steps in plane order (vt_s2_step_of_tap)
+        std::vector<uint16_t> hp(p.size());
+        for (int o = 0; o < cout; ++o)
+            for (int t = 0; t < 9; ++t)
+                for (int i = 0; i < cin; ++i)
+                    hp[(((size_t)(i >> 5) * 9 + vt_s2_step_of_tap(t)) * cout + ((o & ~63) + vt_halo_row_of_cout(o & 63))) * 32 + (i & 31)] = p[((size_t)o * 9 + t) * cin + i];
+        out->wp2 = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
+        if (!out->wp2) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
     }
     if (k == 3 && vt_conv3x3_halo_fp8_supported(cin, cout)) {
         std::vector<uint8_t> p8; std::vector<float> m8;
@@ -470,6 +482,26 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
         if (sc) { h.scX = sc->x; h.scW = sc->wp8; h.scCin = sc->cin; h.bias = sc->bias; }
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_fp8_tiles(Hin, Win); }
         HIPCK(c, launch_halo_fp8(c, h, s), "conv3x3_halo_fp8");
+        return VT_OK;
+    }
+    if (c->s2_halo && w.wp2 && w.k == 3 && stride == 2 && pad == 0 && Hout == Hin / 2 && Wout == Win / 2 && !res16 && !ss && !sc && !xnorm_f32) {
+        Conv3x3S2Args h{};
+        h.X = x; h.Wp = w.wp2; h.bias = w.b; h.res = res32; h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
+        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
+        if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_s2_tiles(Hout, Wout); }
+        if (c->profiling) {
+            vt_context::ProfRec r;
+            r.e0 = c->next_event(); r.e1 = c->next_event();
+            if (!r.e0 || !r.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+            r.flops = 2.0 * B * (double)Hout * Wout * w.cout * 9.0 * w.cin;
+            r.cfg = VT_PROF_S2_HALO;
+            HIPCK(c, hipEventRecord(r.e0, s), "hipEventRecord");
+            HIPCK(c, vt_launch_conv3x3_s2(h, s), "conv3x3_s2");
+            HIPCK(c, hipEventRecord(r.e1, s), "hipEventRecord");
+            c->prof.push_back(r);
+        } else {
+            HIPCK(c, vt_launch_conv3x3_s2(h, s), "conv3x3_s2");
+        }
         return VT_OK;
     }
     if (c->use_halo_conv && w.wp && w.k == 3 && stride == 1 && pad == 1 && Hout == Hin && Wout == Win) {
@@ -743,6 +775,8 @@ EncPlan plan_encoder(const EncoderW& e, int B, int H, int W) {
         if (t4 > ck) ck = t4;
         const int t5 = vt_conv3x3_halo_fp8_tiles(hh, ww);
         if (t5 > ck) ck = t5;
+        const int t6 = vt_conv3x3_s2_tiles(hh, ww);
+        if (t6 > ck) ck = t6;
         if (t1 > ck) ck = t1;
         if (t2 > ck) ck = t2;
         if (ck > p.max_chunks) p.max_chunks = ck;
@@ -881,7 +915,7 @@ int vt_encoder_finalize(vt_context* c) {
         }
         if (i + 1 < e.block_out.size()) {
             char nm[128]; snprintf(nm, sizeof nm, "encoder.down_blocks.%zu.downsamplers.0.conv", i);
-            if ((r = get_conv(c, nm, co, co, 3, &st.down))) return r;
+            if ((r = get_conv(c, nm, co, co, 3, &st.down, true))) return r;
             st.has_down = true;
         }
         e.stages.push_back(st);
@@ -1275,6 +1309,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 10) { c->pv_stream = value != 0; return VT_OK; }
     if (flag == 11) { c->fp8 = value != 0; return VT_OK; }
     if (flag == 12) { c->attn_pv_kernel = value != 0; return VT_OK; }
+    if (flag == 13) { c->s2_halo = value != 0; return VT_OK; }
     if (flag == 7) {
         if (value < 0 || value > 2) return c->fail(VT_ERR_INVALID, "vt_set_flag(7): value %d not in 0..2", value);
         c->attn_mode = value;
@@ -1445,6 +1480,18 @@ int vt_op_conv2d(vt_context* c, const void* x, const void* w, const float* bias,
         h.out_bf16 = (bf16_t*)o16; h.zeros = c->zeros; h.batch = B; h.H = Hin; h.W = Win; h.Cin = Cin; h.Cout = Cout;
         HIPCK(c, launch_halo(c, h, (hipStream_t)stream), "vt_op_conv2d(halo)");
         return VT_OK;
+    }
+    if (c->s2_halo && ksize == 3 && stride == 2 && pad_lo == 0 && pad_hi == 1 && Hin >= 2 && Win >= 2 && vt_conv3x3_s2_supported(Cin, Cout)) {
+        const size_t need = (size_t)Cout * 9 * Cin * 2;
+        if (c->op_scratch_bytes < need) {
+            if (c->op_scratch) (void)hipFree(c->op_scratch);
+            c->op_scratch = nullptr; c->op_scratch_bytes = 0;
+            HIPCK(c, hipMalloc(&c->op_scratch, need), "hipMalloc(op scratch)");
+            c->op_scratch_bytes = need;
+        }
+        HIPCK(c, vt_launch_repack_ohwi_to_s2((const bf16_t*)w, (bf16_t*)c->op_scratch, Cin, Cout, (hipStream_t)stream), "repack");
+        ConvW cw; cw.cin = Cin; cw.cout = Cout; cw.k = 3; cw.wp2 = (const bf16_t*)c->op_scratch; cw.b = bias;
+        return run_conv(c, cw, (const bf16_t*)x, B, Hin, Win, 2, 0, Hout, Wout, res, o32, (bf16_t*)o16, (hipStream_t)stream);
     }
     ConvGemmArgs a{};
     a.X = (const bf16_t*)x; a.W = (const bf16_t*)w; a.bias = bias; a.res = res; a.out_f32 = o32; a.out_bf16 = (bf16_t*)o16;

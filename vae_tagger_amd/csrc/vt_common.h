@@ -225,6 +225,10 @@ __device__ __forceinline__ void vt_gn_epilogue_partials_il(const f32x4 (&v)[TC][
 // run kx-major so that one column shift's halo rows serve all three ky from registers.
 __host__ __device__ inline int vt_halo_step_of_tap(int tap /*0..8*/) { return (tap % 3) * 3 + tap / 3; }
 
+// K-step (inside a 32-channel chunk) at which conv3x3_s2_halo processes filter tap (ky, kx) = (tap / 3, tap % 3): plane-major
+// (plane = (ky & 1, kx & 1)), dx-major inside a plane -- see the table at the top of conv3x3_s2_halo.hip.
+__host__ __device__ inline int vt_s2_step_of_tap(int tap /*0..8*/) { return (int)((0x351786240ULL >> (4 * tap)) & 15); }
+
 // LDS row (inside a wave's 64-cout group) that must hold cout_local, so that MFMA tile i / A-row r' lands on
 // cout_local = (r' & 3) + 4*i + 16*(r' >> 2).  Used by the host and device weight packers.
 __host__ __device__ inline int vt_halo_row_of_cout(int cout_local /*0..63*/) {

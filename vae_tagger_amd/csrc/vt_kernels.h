@@ -53,8 +53,9 @@ constexpr int VT_PROF_ATTN_QK = 10;
 constexpr int VT_PROF_HALO_FP8 = 11;
 constexpr int VT_PROF_ATTN_PV = 12;
 constexpr int VT_PROF_GEMM_FP8 = 13;
-constexpr int VT_PROF_GN_APPLY = 14;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
-constexpr int VT_NUM_PROF_SLOTS = 15;
+constexpr int VT_PROF_S2_HALO = 14;      // stride-2 phase-plane halo conv (conv3x3_s2_halo.hip)
+constexpr int VT_PROF_GN_APPLY = 15;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 16;
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
@@ -130,6 +131,24 @@ bool vt_conv3x3_halo_supported(int Cin, int Cout);
 int vt_conv3x3_halo_config(const Conv3x3Args& a);
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s);
 hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w_ohwi, bf16_t* wp, int Cin, int Cout, hipStream_t s);
+
+// 3x3 stride-2 conv with Downsample2D's (0,1,0,1) padding, phase-plane halo kernel (conv3x3_s2_halo.hip): out = W . x + bias (+ res)
+struct Conv3x3S2Args {
+    const bf16_t* X;        // NHWC bf16 [batch][H][W][Cin]
+    const bf16_t* Wp;       // packed [Cin/32][9 steps (vt_s2_step_of_tap)][Cout rows (vt_halo_row_of_cout)][32] bf16
+    const float* bias;      // [Cout] or null
+    const float* res;       // optional fp32 residual [batch][Ho][Wo][Cout]
+    float* out_f32; bf16_t* out_bf16; f16_t* out_f16;     // at least one; [batch][Ho][Wo][Cout], Ho = H / 2, Wo = W / 2
+    const void* zeros;
+    float* gn_partial; int gn_cpg;                         // optional [batch][tiles][Cout/gn_cpg][3]
+    int batch, H, W, Cin, Cout;
+    int Ho, Wo, tiles_x, ctiles, per_img, ptiles;          // filled by the launcher
+    unsigned long long m_per_img, m_ctiles, m_tiles_x;
+};
+bool vt_conv3x3_s2_supported(int Cin, int Cout);
+int vt_conv3x3_s2_tiles(int Ho, int Wo);                  // GroupNorm partials per image its epilogue writes
+hipError_t vt_launch_conv3x3_s2(const Conv3x3S2Args& a, hipStream_t s);
+hipError_t vt_launch_repack_ohwi_to_s2(const bf16_t* w_ohwi, bf16_t* wp, int Cin, int Cout, hipStream_t s);
 
 // 3x3 stride-1 pad-1 conv on fp8 (OCP e4m3) operands (conv3x3_halo_fp8.hip): out = acc * mult[cout] + bias[cout] (+ residual)
 struct Conv3x3Fp8Args {
