@@ -36,6 +36,9 @@ constexpr int NW = 3, LEAD = NW - 1;         // weight ring
 constexpr int WBUF = BC * HB;                // 8 KB per stage
 constexpr int WPW = BC / 16 / NWV;           // W pieces per wave and K-step: 2
 constexpr int NXB = 3;                       // plane-buffer ring
+#ifndef S2_W_AT
+#define S2_W_AT (TP / 2 - 1)                 // MFMA row group after which a K-step issues its weight DMA
+#endif
 constexpr int XSTRIDE = 289 * HB;            // plane (0,0): 17 x 17 halo rows
 constexpr int SMEM = NXB * XSTRIDE + NW * WBUF;   // 80 064 B
 static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
@@ -240,8 +243,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_s2_halo_kernel(const Conv3x3S2A
                     refill(j, acc[TC - 1][j]);
                     if (j == TP - 1) refill(TP, acc[TC - 1][j]);
                 }
-                if (j == TP / 2 - 1) {
+                if (j == S2_W_AT) {
                     if (!LAST || p + LEAD < 9) issue_w(t + LEAD);
+                }
+                if (j == TP / 2 - 1) {
                     if (p == 0) issue_x(std::integral_constant<int, 2>{}, chunk, slot_of(cm, 2));
                     if (p == 3) issue_x(std::integral_constant<int, 3>{}, chunk, slot_of(cm, 3));
                     if constexpr (!LAST) {
