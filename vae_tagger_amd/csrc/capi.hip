@@ -135,6 +135,7 @@ struct vt_context {
     int fp8 = 0;                    // vt_set_flag(ctx, 11, v): stride-1 3x3 resnet convs on fp8 (e4m3) operands (BASELINE configs[4])
     int halo_occ2 = 3;              // vt_set_flag(ctx, 3, v): two-workgroups-per-CU tile mode of the halo conv
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
+    int attn_fp8 = 1;               // vt_set_flag(ctx, 14, v): in fp8 mode (flag 11) Q.K^T and P.V run on e4m3 operands too (attn_fp8.hip)
     int s2_halo = 1;                // vt_set_flag(ctx, 13, v): stride-2 convs on the phase-plane halo kernel instead of the generic GEMM
     // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
     int* rs_host = nullptr; size_t rs_host_ints = 0; hipEvent_t rs_event = nullptr;
@@ -559,6 +560,7 @@ int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, 
 
 struct AttnScratch {
     bf16_t* qk; bf16_t* vt; f16_t* scores; bf16_t* probs; bf16_t* o;
+    unsigned char* qk8; unsigned char* vt8;     // fp8 attention operands: e4m3(8 q | 8 k) [B][S][2C], e4m3(8 v^T) [B][C][attn_pitch8(S)]
     float* qn; float* kn; float* sd; float* shift; float* rinv; float* part; int* flags;
     int group;
 };
@@ -570,6 +572,13 @@ size_t attn_pitch(int S) {
     const size_t ld = (size_t)(S + 7) / 8 * 8;
     return (ld * 2) % 2048 == 0 ? ld + 2048 + 64 : ld;   // consecutive rows: a different 4-KB block AND a different 256-B sub-block
 }
+// row pitch (bytes) of the e4m3 v^T: S rounded up to 16, off the power-of-two pitches as above
+size_t attn_pitch8(int S) {
+    const size_t ld = (size_t)(S + 15) / 16 * 16;
+    return ld % 2048 == 0 ? ld + 2048 + 64 : ld;
+}
+constexpr float FP8_QK_SCALE = 8.0f;       // q8 | k8 = e4m3(8 q | 8 k), v8 = e4m3(8 v): |values| up to 56 before saturation (status bit 1)
+constexpr float FP8_ATTN_MAX_GAP = 11.0f;  // fp8 mode: numerators exp(s - c) <= e^(gap / 2) = 245 < 448; a looser bound takes the exact row maximum
 // Probabilities (and, on the three-pass path, scores) are materialised for `group` images at a time (one batched launch
 // each for Q.K^T and P.V): as many images as fit a 9.25 GiB budget (1.13 GiB per image at S = 16384), in equal launches.
 int attn_group(int B, int S) {
@@ -592,7 +601,8 @@ size_t attn_scratch_bytes(int B, int S, int C) {
     const size_t ld = attn_pitch(S), G = (size_t)attn_group(B, S);
     return align_up((size_t)B * S * 2 * C * 2) + align_up((size_t)B * C * ld * 2) + align_up(G * S * ld * 2) +
            align_up(G * attn_p_elems(S) * 2) + align_up((size_t)B * S * C * 2) + 5 * align_up((size_t)B * S * 4) +
-           align_up(G * attn_slots_bound(S) * S * 4) + align_up((size_t)B * 4);
+           align_up(G * attn_slots_bound(S) * S * 4) + align_up((size_t)B * 4) + align_up((size_t)B * S * 2 * C) +
+           align_up((size_t)B * C * attn_pitch8(S));
 }
 AttnScratch carve_attn(char* p, int B, int S, int C) {
     const size_t ld = attn_pitch(S), G = (size_t)attn_group(B, S);
@@ -609,7 +619,9 @@ AttnScratch carve_attn(char* p, int B, int S, int C) {
     a.shift = (float*)p; p += align_up((size_t)B * S * 4);
     a.rinv = (float*)p; p += align_up((size_t)B * S * 4);
     a.part = (float*)p; p += align_up(G * attn_slots_bound(S) * S * 4);
-    a.flags = (int*)p;
+    a.flags = (int*)p; p += align_up((size_t)B * 4);
+    a.qk8 = (unsigned char*)p; p += align_up((size_t)B * S * 2 * C);
+    a.vt8 = (unsigned char*)p;
     return a;
 }
 
@@ -633,13 +645,20 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
     a.x_bs = 0; a.w_bs = (long long)S * C; a.o_bs = (long long)C * lp; a.batch = B;
     HIPCK(c, launch_gemm(c, a, s), "attn v proj");
     const float scale = 1.0f / sqrtf((float)C);
+    const bool f8 = c->fp8 && c->attn_fp8 && c->attn_mode != 2 && c->attn_qk_kernel && vt_attn_qk_supported(S, C) && vt_attn_fp8_supported(S, C) &&
+                    (size_t)vt_attn_p8_bytes(S) <= attn_p_elems(S) * 2;
+    const int ld8 = (int)attn_pitch8(S), kext8 = (S + 15) / 16 * 16;
     const int mode = c->attn_mode;                  // 0: exponent shift from operand norms, exact row maximum if flagged;
                                                     // 1: always the exact row maximum; 2: scores -> softmax pass -> P
     if (mode == 0) {
         HIPCK(c, hipMemsetAsync(sc.flags, 0, (size_t)((B + sc.group - 1) / sc.group) * 4, s), "attn flags");
-        HIPCK(c, vt_launch_attn_row_norms(sc.qk, (long long)B * S, C, sc.qn, sc.kn, sc.sd, s), "attn row norms");
-        HIPCK(c, vt_launch_attn_shift(sc.qn, sc.kn, sc.sd, B, S, scale, 120.f, sc.shift, sc.flags, sc.group, s), "attn shift");
+        if (f8) HIPCK(c, vt_launch_attn_row_norms_fp8(sc.qk, (long long)B * S, C, FP8_QK_SCALE, sc.qk8, sc.qn, sc.kn, sc.sd, c->status, s), "attn row norms fp8");
+        else HIPCK(c, vt_launch_attn_row_norms(sc.qk, (long long)B * S, C, sc.qn, sc.kn, sc.sd, s), "attn row norms");
+        HIPCK(c, vt_launch_attn_shift(sc.qn, sc.kn, sc.sd, B, S, scale, f8 ? FP8_ATTN_MAX_GAP : 120.f, sc.shift, sc.flags, sc.group, s), "attn shift");
+    } else if (f8) {
+        HIPCK(c, vt_launch_attn_row_norms_fp8(sc.qk, (long long)B * S, C, FP8_QK_SCALE, sc.qk8, sc.qn, sc.kn, sc.sd, c->status, s), "attn row norms fp8");
     }
+    if (f8) HIPCK(c, vt_launch_attn_vt_to_fp8(sc.vt, (long long)C * lp, lp, sc.vt8, (long long)C * ld8, ld8, S, kext8, C, B, FP8_QK_SCALE, s), "attn v^T fp8");
     for (int b0 = 0; b0 < B; b0 += sc.group) {
         const int nb = (B - b0 < sc.group) ? B - b0 : sc.group;
         const bf16_t* q = sc.qk + (long long)b0 * S * 2 * C;
@@ -665,6 +684,39 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
             const int* gate = mode == 0 ? sc.flags + b0 / sc.group : nullptr;
             k.mode = 1; k.rowout = shift; k.gate = gate; k.gate_expect = 1;
             HIPCK(c, vt_launch_attn_qk(k, s), "attn row max");
+            if (f8) {
+                // fp8 mode: the numerators and the P.V contraction on e4m3 operands (the exact-maximum pass above, when its gate is
+                // open, runs on the bf16 q | k: a shift a few percent off the e4m3 scores' maximum is as good)
+                if ((size_t)4 * nb * S > sc.group * attn_slots_bound(S) * (size_t)S) return c->fail(VT_ERR_WORKSPACE, "attention: segment sums exceed the scratch");
+                AttnQk8Args q8{};
+                q8.qk8 = sc.qk8 + (long long)b0 * S * 2 * C; q8.ldq = 2 * C; q8.qk_bs = (long long)S * 2 * C; q8.S = S; q8.C = C;
+                q8.P8 = (unsigned char*)sc.probs; q8.p_bs = vt_attn_p8_bytes(S); q8.rowin = shift; q8.rowout = sc.part;
+                q8.row_bs = S; q8.split_stride = (long long)nb * S; q8.alpha = scale / (FP8_QK_SCALE * FP8_QK_SCALE); q8.batch = nb; q8.zeros = c->zeros;
+                const int qblocks = nb * ((S + 255) / 256), ktiles = (S + 127) / 128;
+                q8.nsplit = qblocks > 128 ? 1 : qblocks > 64 ? 2 : 4;
+                while (q8.nsplit > 1 && ktiles / q8.nsplit < 4) q8.nsplit >>= 1;
+                AttnPv8Args v8{};
+                v8.P8 = q8.P8; v8.p_bs = q8.p_bs; v8.vt8 = sc.vt8 + (long long)b0 * C * ld8; v8.ldv = ld8; v8.vt_bs = (long long)C * ld8; v8.kext = kext8;
+                v8.rsum = sc.part; v8.row_bs = S; v8.split_stride = (long long)nb * S; v8.o = sc.o + (long long)b0 * S * C; v8.ldo = C; v8.o_bs = (long long)S * C;
+                v8.out_scale = 1.0f / FP8_QK_SCALE; v8.S = S; v8.C = C; v8.batch = nb; v8.zeros = c->zeros;
+                if (c->profiling) {
+                    vt_context::ProfRec r0, r1;
+                    r0.e0 = c->next_event(); r0.e1 = c->next_event(); r1.e0 = r0.e1; r1.e1 = c->next_event();
+                    if (!r0.e0 || !r0.e1 || !r1.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+                    r0.flops = r1.flops = 2.0 * nb * (double)S * S * C;
+                    r0.cfg = VT_PROF_ATTN_QK8; r1.cfg = VT_PROF_ATTN_PV8;
+                    HIPCK(c, hipEventRecord(r0.e0, s), "hipEventRecord");
+                    HIPCK(c, vt_launch_attn_qk_fp8(q8, s), "attn exp scores fp8");
+                    HIPCK(c, hipEventRecord(r0.e1, s), "hipEventRecord");
+                    HIPCK(c, vt_launch_attn_pv_fp8(v8, s), "attn pv fp8");
+                    HIPCK(c, hipEventRecord(r1.e1, s), "hipEventRecord");
+                    c->prof.push_back(r0); c->prof.push_back(r1);
+                } else {
+                    HIPCK(c, vt_launch_attn_qk_fp8(q8, s), "attn exp scores fp8");
+                    HIPCK(c, vt_launch_attn_pv_fp8(v8, s), "attn pv fp8");
+                }
+                continue;
+            }
             k.mode = 2; k.P = sc.probs; k.ldp = lp; k.p_bs = (long long)S * lp; k.rowin = shift; k.rowout = rinv; k.gate = nullptr;
             frag_pv = c->attn_pv_kernel && vt_attn_pv_supported(S, C);
             if (frag_pv) { k.p_frag = 1; k.p_bs = vt_attn_pt_elems(S); }
@@ -1310,6 +1362,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 11) { c->fp8 = value != 0; return VT_OK; }
     if (flag == 12) { c->attn_pv_kernel = value != 0; return VT_OK; }
     if (flag == 13) { c->s2_halo = value != 0; return VT_OK; }
+    if (flag == 14) { c->attn_fp8 = value != 0; return VT_OK; }
     if (flag == 7) {
         if (value < 0 || value > 2) return c->fail(VT_ERR_INVALID, "vt_set_flag(7): value %d not in 0..2", value);
         c->attn_mode = value;

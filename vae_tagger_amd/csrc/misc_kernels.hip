@@ -1,4 +1,6 @@
 // conv_in (3 -> C0 channels, fp32 direct) and the row softmax of the unfused attention path.
+#include <type_traits>
+
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -618,6 +620,48 @@ __global__ __launch_bounds__(256) void attn_row_norms_kernel(const bf16_t* __res
     if (lane == 0) { qn[row] = a; kn[row] = b; sd[row] = d; }
 }
 
+// the same with the fp8 attention's operands as a by-product: q8 | k8 = e4m3(scale q | scale k) (saturated at +-448; a clamp raises
+// status bit 1), and the norms are those of the QUANTISED values -- the Cauchy-Schwarz bound of the exponent shift then holds for
+// the operands the MFMA actually multiplies
+__global__ __launch_bounds__(256) void attn_row_norms_fp8_kernel(const bf16_t* __restrict__ qk, long long rows, int C, float scale,
+                                                                 unsigned char* __restrict__ qk8, float* __restrict__ qn,
+                                                                 float* __restrict__ kn, float* __restrict__ sd, int* __restrict__ status) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const bf16_t* q = qk + row * 2 * C;
+    unsigned char* o = qk8 + row * 2 * C;
+    const float inv = 1.0f / scale;
+    float a = 0.f, b = 0.f, d = 0.f, amax = 0.f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (int c = lane * 8; c < C; c += 512) {
+        const bf16x8 qv = *(const bf16x8*)(q + c), kv = *(const bf16x8*)(q + C + c);
+        int qw[2] = {0, 0}, kw[2] = {0, 0};
+        // element pair p of the eight -> 16-bit half (p & 1) of word (p >> 1); the half selector of the conversions is an immediate
+        auto pair = [&](auto p_tag) {
+            constexpr int P = decltype(p_tag)::value;
+            constexpr bool HI = (P & 1) != 0;
+            float x0 = (float)qv[2 * P] * scale, x1 = (float)qv[2 * P + 1] * scale, y0 = (float)kv[2 * P] * scale, y1 = (float)kv[2 * P + 1] * scale;
+            amax = fmaxf(fmaxf(fabsf(x0), fabsf(x1)), fmaxf(fmaxf(fabsf(y0), fabsf(y1)), amax));
+            x0 = __builtin_amdgcn_fmed3f(x0, -448.f, 448.f); x1 = __builtin_amdgcn_fmed3f(x1, -448.f, 448.f);
+            y0 = __builtin_amdgcn_fmed3f(y0, -448.f, 448.f); y1 = __builtin_amdgcn_fmed3f(y1, -448.f, 448.f);
+            qw[P >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, qw[P >> 1], HI);
+            kw[P >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(y0, y1, kw[P >> 1], HI);
+            const f32x2 xq = __builtin_amdgcn_cvt_pk_f32_fp8(qw[P >> 1], HI), yq = __builtin_amdgcn_cvt_pk_f32_fp8(kw[P >> 1], HI);
+            const float u0 = xq[0] * inv, u1 = xq[1] * inv, w0 = yq[0] * inv, w1 = yq[1] * inv;
+            a += u0 * u0 + u1 * u1; b += w0 * w0 + w1 * w1; d += u0 * w0 + u1 * w1;
+        };
+        pair(std::integral_constant<int, 0>{}); pair(std::integral_constant<int, 1>{});
+        pair(std::integral_constant<int, 2>{}); pair(std::integral_constant<int, 3>{});
+        *(int2*)(o + c) = make_int2(qw[0], qw[1]);
+        *(int2*)(o + C + c) = make_int2(kw[0], kw[1]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); d += __shfl_xor(d, off); }
+    if (lane == 0) { qn[row] = a; kn[row] = b; sd[row] = d; }
+    if (status && amax > 448.f) atomicOr(status, 2);
+}
+
 // one block per image: c_i and the "bound too loose" flag of the group the image belongs to
 __global__ __launch_bounds__(1024) void attn_shift_kernel(const float* __restrict__ qn, const float* __restrict__ kn,
                                                           const float* __restrict__ sd, int S, float alpha, float max_gap,
@@ -673,6 +717,12 @@ __global__ __launch_bounds__(256) void attn_row_reduce_kernel(const float* __res
 hipError_t vt_launch_attn_row_norms(const bf16_t* qk, long long rows, int C, float* qn, float* kn, float* sd, hipStream_t s) {
     if (!qk || !qn || !kn || !sd || rows <= 0 || rows > 0x7fffffffLL || C <= 0 || (C % 8)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(attn_row_norms_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, qk, rows, C, qn, kn, sd);
+    return hipGetLastError();
+}
+hipError_t vt_launch_attn_row_norms_fp8(const bf16_t* qk, long long rows, int C, float scale, unsigned char* qk8, float* qn, float* kn, float* sd,
+                                        int* status, hipStream_t s) {
+    if (!qk || !qk8 || !qn || !kn || !sd || rows <= 0 || rows > 0x7fffffffLL || C <= 0 || (C % 8) || !(scale > 0.f)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_row_norms_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, qk, rows, C, scale, qk8, qn, kn, sd, status);
     return hipGetLastError();
 }
 hipError_t vt_launch_attn_shift(const float* qn, const float* kn, const float* sd, int images, int S, float alpha, float max_gap,

@@ -54,8 +54,10 @@ constexpr int VT_PROF_HALO_FP8 = 11;
 constexpr int VT_PROF_ATTN_PV = 12;
 constexpr int VT_PROF_GEMM_FP8 = 13;
 constexpr int VT_PROF_S2_HALO = 14;      // stride-2 phase-plane halo conv (conv3x3_s2_halo.hip)
-constexpr int VT_PROF_GN_APPLY = 15;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
-constexpr int VT_NUM_PROF_SLOTS = 16;
+constexpr int VT_PROF_ATTN_QK8 = 15;     // fp8 Q.K^T / P.V (attn_fp8.hip)
+constexpr int VT_PROF_ATTN_PV8 = 16;
+constexpr int VT_PROF_GN_APPLY = 17;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 18;
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
@@ -95,6 +97,40 @@ bool vt_attn_pv_supported(int S, int C);
 __host__ __device__ inline long long vt_attn_pt_slab_stride(int S) { return (long long)((S + 63) / 64) * 2048 + 1152; }
 long long vt_attn_pt_elems(int S);
 hipError_t vt_launch_attn_pv(const AttnPvArgs& a, hipStream_t s);
+
+// ---- the same two contractions on fp8 (e4m3) operands (attn_fp8.hip; vt_set_flag 11 + 14)
+struct AttnQk8Args {
+    const unsigned char* qk8; int ldq; long long qk_bs;   // [S][ldq] e4m3 bytes: q8 (C bytes) | k8 (C bytes) per row, batch stride qk_bs
+    int S, C;
+    unsigned char* P8; long long p_bs;                    // fragment-ordered e4m3 P: vt_attn_p8_bytes(S) per image
+    const float* rowin;                                   // per-row exponent shift [batch][row_bs]
+    float* rowout;                                        // four segment sums per row, [4][split_stride] of [batch][row_bs]
+    long long row_bs, split_stride;
+    float alpha;                                          // scale applied to the e4m3 dot product (1 / (sqrt(C) * qscale * kscale))
+    int batch, nsplit;
+    const void* zeros;
+};
+struct AttnPv8Args {
+    const unsigned char* P8; long long p_bs;
+    const unsigned char* vt8; int ldv; long long vt_bs;   // v^T [C][ldv] e4m3 (keys contiguous); keys >= kext are not read (zero page)
+    int kext;
+    const float* rsum; long long row_bs, split_stride;
+    bf16_t* o; int ldo; long long o_bs;                   // [S][ldo] bf16
+    float out_scale;                                      // 1 / vscale
+    int S, C, batch;
+    const void* zeros;
+};
+bool vt_attn_fp8_supported(int S, int C);
+// bytes between consecutive 32-query slabs of the fragment-ordered e4m3 P: 128-key blocks x 4 KB, plus 2304 B (see vt_attn_pt_slab_stride)
+__host__ __device__ inline long long vt_attn_p8_slab_stride(int S) { return (long long)((S + 127) / 128) * 4096 + 2304; }
+long long vt_attn_p8_bytes(int S);
+hipError_t vt_launch_attn_qk_fp8(const AttnQk8Args& a, hipStream_t s);
+hipError_t vt_launch_attn_pv_fp8(const AttnPv8Args& a, hipStream_t s);
+hipError_t vt_launch_attn_vt_to_fp8(const bf16_t* vt, long long vt_bs, int ldv, unsigned char* v8, long long v8_bs, int ld8, int S, int kext,
+                                    int C, int batch, float scale, hipStream_t s);
+// row norms of q | k as attn_row_norms, taken from the e4m3(scale x) values this kernel also writes (qk8: [rows][2C] bytes)
+hipError_t vt_launch_attn_row_norms_fp8(const bf16_t* qk, long long rows, int C, float scale, unsigned char* qk8, float* qn, float* kn, float* sd,
+                                        int* status, hipStream_t s);
 
 // 3x3 stride-1 pad-1 conv, halo-tile kernel (conv3x3_halo.hip)
 struct Conv3x3Args {
