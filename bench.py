@@ -49,8 +49,8 @@ def parse():
                    help="BASELINE configs[3]: same-shape batches drawn from the reference's 512..1024 step-64 aspect buckets")
     p.add_argument("--bucket-batch", type=int, default=8, help="images per same-shape batch in --bucketed mode")
     p.add_argument("--fp8", action="store_true",
-                   help="BASELINE configs[4]: the stride-1 3x3 resnet convs on fp8 (e4m3) operands / fp8 MFMA (vt_set_flag 11); opt-in mode, "
-                        "logits within 1e-2 of the CPU reference, latents ~1e-1")
+                   help="BASELINE configs[4]: the 3x3 convs of the resnet / downsample stack and the attention's Q.K^T / P.V on fp8 (e4m3) "
+                        "operands / fp8 MFMA (vt_set_flag 11); opt-in mode, logits within 1e-2 of the CPU reference, latents ~1e-1")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-also", action="store_true", help="skip the configs[4] / configs[3] legs attached to the default run's line")
     p.add_argument("--generic-conv", action="store_true", help="A/B: disable the halo-tile 3x3 kernel")
@@ -375,7 +375,7 @@ def main():
         res = {
             "metric": ("images/sec encode+tag, bucketed 512..1024 bf16" if a.bucketed else
                        "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16").replace(
-                           "bf16", "fp8 (3x3 convs; rest bf16)" if a.fp8 else "bf16").replace(
+                           "bf16", "fp8 (3x3 convs + attention GEMMs; projections, conv_in / conv_out bf16)" if a.fp8 else "bf16").replace(
                            "1024^2", "1024^2" if (a.height, a.width) == (1024, 1024) else f"{a.width}x{a.height}"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_step_without_events": round(elapsed_plain / a.steps * 1e3, 3),
@@ -406,7 +406,7 @@ def main():
         ips8 = B * K2 / e8
         fimg = pipe.flops_per_image(a.height, a.width)
         also["configs4_fp8_per_gpu"] = {
-            "workload": f"configs[4] (per GPU): batch {B}/GPU {a.width}x{a.height} encode+tag, {a.tags} tags, 3x3 convs on e4m3 operands (vt_set_flag 11)",
+            "workload": f"configs[4] (per GPU): batch {B}/GPU {a.width}x{a.height} encode+tag, {a.tags} tags, 3x3 convs + Q.K^T / P.V on e4m3 operands (vt_set_flag 11)",
             "value": round(ips8, 3), "unit": "images/sec", "steps": K2, "warmup": W2, "ms_per_step": round(e8 / K2 * 1e3, 3), "dtype": "fp8",
             "vt_status": st8, "identical_to_the_batched_result": same8,
             "roofline": {k: roof8[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms", "traffic", "traffic_source", "per_config")},

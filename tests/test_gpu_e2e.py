@@ -16,7 +16,7 @@ TOL_LOGIT_F32 = 1e-3        # decoder runs in fp32: within 1e-3 (observed ~1e-5)
 # fp8 mode (configs[4]) claims the LOGITS (1e-2); its latents are outside north_star's tolerance by design.  These two are regression
 # bounds at what is observed (max 0.10-0.12, rms 0.021 over 256^2 .. 1024^2 and all 16 images of the bench batch), not a parity claim.
 FP8_LATENT_MAX, FP8_LATENT_RMS = 0.13, 0.025
-FP8_ATTN_TOL = 1.5e-2          # attention output (+ residual) on e4m3 P against fp32 attention of the same e4m3 q, k, v (observed below)
+FP8_ATTN_TOL = 8e-3          # attention output (+ residual) on e4m3 P against fp32 attention of the same e4m3 q, k, v (observed below)
 
 
 @pytest.fixture(scope="module")
@@ -476,8 +476,8 @@ def test_mid_block_attention_on_fp8_operands(gain, S):
     v_mfma_scale_f32_16x16x128_f8f6f4.  Checked against fp32 attention of the SAME e4m3-rounded q, k, v (what the kernels multiply):
     the remaining difference is the e4m3 rounding of P (3 significand bits per numerator, averaged over the keys of a row) and the
     bf16 output.  Shapes: one / several 128-key tiles, ragged tails, key sweeps split over 2 / 4 workgroups (S = 1024, 2048), and
-    gains that push a launch group over the fp8 gap limit (exact row maximum path).  Modes 0 and 1 agree; the flag-14 switch puts
-    the same launch back on the bf16 kernels."""
+    gains that make rows peaky.  The exponent shift is always the exact row maximum of the e4m3 scores (a first sweep of the Q.K^T
+    kernel), so vt_set_flag 7's modes 0 and 1 are the same launches; the flag-14 switch puts the launch back on the bf16 kernels."""
     import ctypes
     from vae_tagger_amd.diffusers_vae_loader import get_diffusers_vae_config, load_diffusers_vae_from_config
     from _util import vp
@@ -523,10 +523,12 @@ def test_mid_block_attention_on_fp8_operands(gain, S):
     print(f"fp8 attention S={S} gain={gain}: max|d| vs fp32 attention of the e4m3 operands: mode 0 {e0:.3e}, mode 1 {e1:.3e}; "
           f"rms {(outs['fp8 mode 0'] - ref).pow(2).mean().sqrt():.3e}")
     # flat rows (gain 1: the synthetic weights, u - l ~ 8) average the 3-bit rounding of P over hundreds of keys; rows that a few keys
-    # dominate (gain 3, 6) keep up to e4m3's half step (2^-4 relative) of |v| ~ 1 -- the price of e4m3 P, bounded here, not hidden
-    tol, tol_rms = (FP8_ATTN_TOL, 3e-3) if gain == 1.0 else (1e-1, 1e-2)
+    # dominate (gain 3, 6) keep more of e4m3's half step (2^-4 relative): observed 1.4 - 1.6e-2 against 1 - 5e-3 -- the price of e4m3 P,
+    # bounded here, not hidden (with a shift bounded from operand norms instead of the exact maximum it was 3 - 7e-2)
+    tol, tol_rms = (FP8_ATTN_TOL, 2e-3) if gain == 1.0 else (3e-2, 3e-3)
     rms = (outs["fp8 mode 0"] - ref).pow(2).mean().sqrt().item()
     assert torch.isfinite(outs["fp8 mode 0"]).all() and e0 <= tol and e1 <= tol and rms <= tol_rms
+    assert torch.equal(outs["fp8 mode 0"], outs["fp8 mode 1"])
     assert torch.isfinite(outs["bf16 kernels"]).all() and not torch.equal(outs["bf16 kernels"], outs["fp8 mode 0"])
     if gain == 1.0:         # (flag 14 off: bf16 q, k, v, P -- the e4m3 rounding of the reference's operands is what shows here)
         assert (outs["bf16 kernels"] - ref).abs().max().item() <= 6e-2

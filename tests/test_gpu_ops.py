@@ -257,6 +257,45 @@ def test_fp8_conv_matches_torch_on_the_same_quantised_operands(ops, B, Cin, Cout
     assert torch.allclose(got, ref_of(x), rtol=1e-4, atol=3e-3), (got - ref_of(x)).abs().max()
 
 
+def test_fp8_mfma_block_sum_keeps_a_bounded_window_below_its_largest_product(ops):
+    """Isolates what the saturated case above tolerates (atol 3e-3): v_mfma_scale_f32_32x32x64_f8f6f4 does not add the 64 products
+    of a K-block in fp32 -- it aligns them to the block's LARGEST product and keeps a bounded number of bits below it.
+    One output, one K-block (Cin = 64, centre tap only), every operand exactly representable in e4m3: channel 0 carries one big
+    product B = 448 x 448 (in quantised units), the other 63 channels the product s each.  In fp32 the sum is B + 63 s exactly
+    (all values < 2^24).  Observed on gfx950: for s >= 2^-14.6 B the result is exact; below that exactly SEVEN of the 63 small
+    products are lost (B + 56 s comes back) -- the companions of the big product in its group of eight, the other groups add up
+    exactly; without the big product the same small products always sum exactly.  Asserted: products within 2^-13 of the block's
+    largest are kept exactly and the total error stays below 2^-12 of it, so that a different part or compiler would show."""
+    Cin, Cout, H, W = 64, 128, 8, 32
+    big = 448.0
+    rows = []
+    for j in range(0, 13):
+        s_x = 2.0 ** (j - (j // 2))          # split s = 2^j between the two operands (both stay e4m3-exact powers of two)
+        s_w = 2.0 ** (j // 2)
+        for with_big in (True, False):
+            xq = torch.full((1, Cin, H, W), s_x)            # quantised-domain values e4m3(8 x) should hold
+            wq = torch.zeros(Cout, Cin, 3, 3)
+            wq[:, :, 1, 1] = s_w
+            if with_big:
+                xq[:, 0] = big
+            wq[:, 0, 1, 1] = big                             # (per-cout absmax = 448 -> weight scale exactly 1)
+            got = ops.conv3x3_fp8(xq / 8.0, wq)              # x = xq / 8 exactly; out = sum(xq wq) / 8
+            exact = ((big * big if with_big else s_x * big) + 63.0 * s_x * s_w) / 8.0
+            v = got[0, 0, 3, 7].item()
+            assert (got == v).all()                          # every output sees the same block
+            rows.append((j, with_big, exact, v))
+    for j, with_big, exact, v in rows:
+        print(f"s = 2^{j:2d}  {'B + 63 s' if with_big else '448 s_x + 63 s':14s} exact {exact:12.3f}  device {v:12.3f}  diff {v - exact:9.3f}")
+    B8 = big * big / 8.0
+    for j, with_big, exact, v in rows:
+        if not with_big:
+            assert v == exact, (j, exact, v)                 # no big product: nothing to align to, the small ones add exactly
+        else:
+            assert abs(v - exact) <= B8 * 2.0 ** -12, (j, exact, v)
+            if 2.0 ** j >= big * big * 2.0 ** -13:
+                assert v == exact, (j, exact, v)             # products within 2^-13 of the largest are kept exactly
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 128, 34, 50), (1, 256, 16, 16), (1, 512, 18, 22)])
 def test_fp8_stride2_conv_matches_torch_on_the_same_quantised_operands(ops, B, C, H, W):
     """Downsample2D's conv (pad (0,1,0,1), stride 2) on e4m3 operands: conv_gemm_kernel<..., F8> with

@@ -3,8 +3,8 @@
 // Same division of labour as attn_qk.hip / attn_pv.hip (Q slab in registers, keys streamed through LDS, a wave owns whole rows of
 // the score matrix; P stored in MFMA fragment order and loaded straight into registers by P.V, only v^T through LDS), re-shaped for
 // v_mfma_scale_f32_16x16x128_f8f6f4 (both scales 2^0): four times the K per instruction at twice the cycles.
-//   * operands: q8 | k8 = e4m3(8 q | 8 k) from the row-norms pass (misc_kernels.hip), v8^T = e4m3(8 v^T); P8 = e4m3(exp(s - c))
-//     (numerators <= e^(gap/2) <= 245 with the fp8 mode's gap limit of 11, clamped at 448 regardless);
+//   * operands: q8 | k8 = e4m3(8 q | 8 k) (misc_kernels.hip), v8^T = e4m3(8 v^T); P8 = e4m3(256 exp(s - max_row s)): the exponent shift
+//     is the EXACT row maximum of the e4m3 scores, from a first sweep of this kernel (MODE 1, no exp / convert / store);
 //   * a lane of the 16x16x128 MFMA holds 32 consecutive k-bytes of its row (two ds_read_b128 / two 16-B global loads);
 //   * Q.K^T key tile = 128 keys x 512 B = 64 KB (two buffers); LDS row R = 16 m + r of the tile holds key 32 (r >> 2) + 16 (m >> 2) +
 //     4 (m & 3) + (r & 3) of the 128-key block: the accumulators of lane (q4, .) over the tile's eight MFMA row tiles are then 32
@@ -42,6 +42,10 @@ __device__ __forceinline__ i32x8 cat8(i32x4 lo, i32x4 hi) { return i32x8{lo[0], 
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Q.K^T: P8 fragments + segment sums
+// MODE 1: no P; rowout[row] = max_key alpha * q8.k8 (the exact exponent shift: e4m3's range, 2^-6 .. 448 for normal numbers, is too
+// short for a shift bounded from operand norms -- a row whose maximum sits e^-5 below the bound would keep one significant bit);
+// MODE 3: P8 = e4m3(pscale * exp(alpha * q8.k8 - rowin[row])) in fragment order + segment sums of the rounded values.
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 key tiles
     const int lane = threadIdx.x & 63;
@@ -71,8 +75,9 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = row0 + j * 16 + fr;
-        rv[j] = 0.f;
-        sh2[j] = row < a.S ? a.rowin[(long long)b * a.row_bs + row] * 1.44269504f : 0.f;
+        rv[j] = MODE == 1 ? -__builtin_inff() : 0.f;
+        // (pscale = 2^k rides in the exponent: exp2(x - (shift log2 e - k)))
+        sh2[j] = (MODE == 3 && row < a.S) ? a.rowin[(long long)b * a.row_bs + row] * 1.44269504f - a.pscale_log2 : 0.f;
     }
     const float alpha2 = a.alpha * 1.44269504f;
 
@@ -120,6 +125,12 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (FULL || key0 + 16 * (m >> 2) + 4 * (m & 3) + r < a.S) rv[j] = fmaxf(rv[j], acc[m][j][r] * a.alpha);
+                    continue;
+                }
                 float e[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -157,16 +168,18 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
     auto epilogue = [&](int kt) __attribute__((always_inline)) {
         if (kt * KT + KT <= a.S) epilogue_t(kt, std::true_type{});
         else epilogue_t(kt, std::false_type{});
+        if constexpr (MODE == 3) {
 #pragma unroll
-        for (int seg = 0; seg < 4; ++seg)
-            if (kt + 1 == segb[seg + 1] && segb[seg + 1] > segb[seg]) write_segment(seg, false);
+            for (int seg = 0; seg < 4; ++seg)
+                if (kt + 1 == segb[seg + 1] && segb[seg + 1] > segb[seg]) write_segment(seg, false);
+        }
     };
 
     // waves w and w + 4 share a SIMD and run their DMA issue / epilogue on opposite sides of the MFMA block (attn_qk.hip)
     const bool late = (wave & 4) != 0;
     const int seg0 = ksp * (4 / nsplit), seg1 = (ksp + 1) * (4 / nsplit);
-    const int kt0 = segb[seg0], nkt = segb[seg1];
-    const bool counted = row0 < a.S;                       // this wave issues exactly 4 stores per epilogue
+    const int kt0 = MODE == 3 ? segb[seg0] : 0, nkt = MODE == 3 ? segb[seg1] : nkt_all;
+    const bool counted = MODE == 3 && row0 < a.S;          // this wave issues exactly 4 stores per epilogue
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
         asm volatile("" ::: "memory");
         if (late) {
             if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
-            if (kt > kt0) { epilogue(kt - 1); store_held(kt - 1); }
+            if (kt > kt0) { epilogue(kt - 1); if (MODE == 3) store_held(kt - 1); }
         }
         const char* ks_base = smem + (kt & 1) * KBUF;
         // key fragments (32 B per lane = two ds_read_b128) through a ring of register sets, read AHEAD positions before their MFMAs
@@ -204,16 +217,28 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
         if (!late) {
             if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
             epilogue(kt);
-            store_held(kt);
+            if (MODE == 3) store_held(kt);
         }
     }
     if (nkt > kt0 && late) {
         epilogue(nkt - 1);
-        store_held(nkt - 1);
+        if (MODE == 3) store_held(nkt - 1);
     }
+    if constexpr (MODE == 3) {
 #pragma unroll
-    for (int seg = 0; seg < 4; ++seg)
-        if (seg >= seg0 && seg < seg1 && segb[seg + 1] == segb[seg]) write_segment(seg, true);
+        for (int seg = 0; seg < 4; ++seg)
+            if (seg >= seg0 && seg < seg1 && segb[seg + 1] == segb[seg]) write_segment(seg, true);
+        return;
+    }
+    // MODE 1: the four fq lanes of a row hold its other keys
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float v = rv[j];
+        v = fmaxf(v, __shfl_xor(v, 16));
+        v = fmaxf(v, __shfl_xor(v, 32));
+        const int row = row0 + j * 16 + fr;
+        if (fq == 0 && row < a.S) a.rowout[(long long)b * a.row_bs + row] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -353,17 +378,23 @@ bool vt_attn_fp8_supported(int S, int C) { return C == D && S > 0; }
 long long vt_attn_p8_bytes(int S) { return (long long)((S + 31) / 32) * vt_attn_p8_slab_stride(S); }
 
 hipError_t vt_launch_attn_qk_fp8(const AttnQk8Args& a, hipStream_t s) {
-    if (!a.qk8 || !a.P8 || !a.rowin || !a.rowout || !a.zeros || a.batch <= 0 || !vt_attn_fp8_supported(a.S, a.C)) return hipErrorInvalidValue;
-    if ((a.ldq % 16) || (a.qk_bs % 16) || a.row_bs < a.S || (a.p_bs % 16) || a.p_bs < vt_attn_p8_bytes(a.S)) return hipErrorInvalidValue;
+    if (!a.qk8 || !a.rowout || !a.zeros || a.batch <= 0 || !vt_attn_fp8_supported(a.S, a.C) || (a.mode != 1 && a.mode != 3)) return hipErrorInvalidValue;
+    if ((a.ldq % 16) || (a.qk_bs % 16) || a.row_bs < a.S) return hipErrorInvalidValue;
+    if (a.mode == 3 && (!a.P8 || !a.rowin || (a.p_bs % 16) || a.p_bs < vt_attn_p8_bytes(a.S))) return hipErrorInvalidValue;
+    if (a.mode == 1 && a.nsplit > 1) return hipErrorInvalidValue;
     if ((long long)a.S * a.ldq >= (1LL << 31)) return hipErrorInvalidValue;
     if (a.nsplit > 1 && a.nsplit != 2 && a.nsplit != 4) return hipErrorInvalidValue;
-    if (a.split_stride < (long long)a.batch * a.row_bs) return hipErrorInvalidValue;
+    if (a.mode == 3 && a.split_stride < (long long)a.batch * a.row_bs) return hipErrorInvalidValue;
     const long long nblk = (long long)((a.S + QB - 1) / QB) * a.batch * (a.nsplit > 1 ? a.nsplit : 1);
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> attr_done{0};
-    hipError_t ea = vt_once_per_device(attr_done, [&] { return hipFuncSetAttribute((const void*)attn_qk_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF); });
+    hipError_t ea = vt_once_per_device(attr_done, [&] {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_qk_fp8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF);
+        return e != hipSuccess ? e : hipFuncSetAttribute((const void*)attn_qk_fp8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF);
+    });
     if (ea != hipSuccess) return ea;
-    hipLaunchKernelGGL(attn_qk_fp8_kernel, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
+    if (a.mode == 1) hipLaunchKernelGGL(attn_qk_fp8_kernel<1>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
+    else hipLaunchKernelGGL(attn_qk_fp8_kernel<3>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
     return hipGetLastError();
 }
 

@@ -578,7 +578,7 @@ size_t attn_pitch8(int S) {
     return ld % 2048 == 0 ? ld + 2048 + 64 : ld;
 }
 constexpr float FP8_QK_SCALE = 8.0f;       // q8 | k8 = e4m3(8 q | 8 k), v8 = e4m3(8 v): |values| up to 56 before saturation (status bit 1)
-constexpr float FP8_ATTN_MAX_GAP = 11.0f;  // fp8 mode: numerators exp(s - c) <= e^(gap / 2) = 245 < 448; a looser bound takes the exact row maximum
+constexpr float FP8_P_SCALE_LOG2 = 8.0f;   // P8 = e4m3(256 exp(s - max)): numerators <= 256 < 448, e4m3's normal range reaches 6e-5 of the row maximum
 // Probabilities (and, on the three-pass path, scores) are materialised for `group` images at a time (one batched launch
 // each for Q.K^T and P.V): as many images as fit a 9.25 GiB budget (1.13 GiB per image at S = 16384), in equal launches.
 int attn_group(int B, int S) {
@@ -650,13 +650,13 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
     const int ld8 = (int)attn_pitch8(S), kext8 = (S + 15) / 16 * 16;
     const int mode = c->attn_mode;                  // 0: exponent shift from operand norms, exact row maximum if flagged;
                                                     // 1: always the exact row maximum; 2: scores -> softmax pass -> P
-    if (mode == 0) {
+    if (f8) {
+        // (q8 | k8 come out of the row-norms pass; the norms themselves are not used: the fp8 path takes the exact row maximum)
+        HIPCK(c, vt_launch_attn_row_norms_fp8(sc.qk, (long long)B * S, C, FP8_QK_SCALE, sc.qk8, sc.qn, sc.kn, sc.sd, c->status, s), "attn q|k -> e4m3");
+    } else if (mode == 0) {
         HIPCK(c, hipMemsetAsync(sc.flags, 0, (size_t)((B + sc.group - 1) / sc.group) * 4, s), "attn flags");
-        if (f8) HIPCK(c, vt_launch_attn_row_norms_fp8(sc.qk, (long long)B * S, C, FP8_QK_SCALE, sc.qk8, sc.qn, sc.kn, sc.sd, c->status, s), "attn row norms fp8");
-        else HIPCK(c, vt_launch_attn_row_norms(sc.qk, (long long)B * S, C, sc.qn, sc.kn, sc.sd, s), "attn row norms");
-        HIPCK(c, vt_launch_attn_shift(sc.qn, sc.kn, sc.sd, B, S, scale, f8 ? FP8_ATTN_MAX_GAP : 120.f, sc.shift, sc.flags, sc.group, s), "attn shift");
-    } else if (f8) {
-        HIPCK(c, vt_launch_attn_row_norms_fp8(sc.qk, (long long)B * S, C, FP8_QK_SCALE, sc.qk8, sc.qn, sc.kn, sc.sd, c->status, s), "attn row norms fp8");
+        HIPCK(c, vt_launch_attn_row_norms(sc.qk, (long long)B * S, C, sc.qn, sc.kn, sc.sd, s), "attn row norms");
+        HIPCK(c, vt_launch_attn_shift(sc.qn, sc.kn, sc.sd, B, S, scale, 120.f, sc.shift, sc.flags, sc.group, s), "attn shift");
     }
     if (f8) HIPCK(c, vt_launch_attn_vt_to_fp8(sc.vt, (long long)C * lp, lp, sc.vt8, (long long)C * ld8, ld8, S, kext8, C, B, FP8_QK_SCALE, s), "attn v^T fp8");
     for (int b0 = 0; b0 < B; b0 += sc.group) {
@@ -682,23 +682,26 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
             k.q = q; k.k = q + C; k.S = S; k.C = C; k.ldq = 2 * C; k.qk_bs = (long long)S * 2 * C;
             k.row_bs = S; k.alpha = scale; k.batch = nb; k.zeros = c->zeros;
             const int* gate = mode == 0 ? sc.flags + b0 / sc.group : nullptr;
-            k.mode = 1; k.rowout = shift; k.gate = gate; k.gate_expect = 1;
-            HIPCK(c, vt_launch_attn_qk(k, s), "attn row max");
             if (f8) {
-                // fp8 mode: the numerators and the P.V contraction on e4m3 operands (the exact-maximum pass above, when its gate is
-                // open, runs on the bf16 q | k: a shift a few percent off the e4m3 scores' maximum is as good)
+                // fp8 mode: both contractions on e4m3 operands.  The exponent shift is the exact row maximum of the e4m3 scores (a first
+                // sweep of the same kernel without exp / convert / store): numerators <= 1, stored as e4m3(256 x)
                 if ((size_t)4 * nb * S > sc.group * attn_slots_bound(S) * (size_t)S) return c->fail(VT_ERR_WORKSPACE, "attention: segment sums exceed the scratch");
                 AttnQk8Args q8{};
                 q8.qk8 = sc.qk8 + (long long)b0 * S * 2 * C; q8.ldq = 2 * C; q8.qk_bs = (long long)S * 2 * C; q8.S = S; q8.C = C;
                 q8.P8 = (unsigned char*)sc.probs; q8.p_bs = vt_attn_p8_bytes(S); q8.rowin = shift; q8.rowout = sc.part;
                 q8.row_bs = S; q8.split_stride = (long long)nb * S; q8.alpha = scale / (FP8_QK_SCALE * FP8_QK_SCALE); q8.batch = nb; q8.zeros = c->zeros;
+                q8.pscale_log2 = FP8_P_SCALE_LOG2;
+                q8.mode = 1; q8.rowout = shift; q8.nsplit = 1;
+                HIPCK(c, vt_launch_attn_qk_fp8(q8, s), "attn row max fp8");
+                q8.mode = 3; q8.rowout = sc.part;
                 const int qblocks = nb * ((S + 255) / 256), ktiles = (S + 127) / 128;
                 q8.nsplit = qblocks > 128 ? 1 : qblocks > 64 ? 2 : 4;
                 while (q8.nsplit > 1 && ktiles / q8.nsplit < 4) q8.nsplit >>= 1;
                 AttnPv8Args v8{};
                 v8.P8 = q8.P8; v8.p_bs = q8.p_bs; v8.vt8 = sc.vt8 + (long long)b0 * C * ld8; v8.ldv = ld8; v8.vt_bs = (long long)C * ld8; v8.kext = kext8;
                 v8.rsum = sc.part; v8.row_bs = S; v8.split_stride = (long long)nb * S; v8.o = sc.o + (long long)b0 * S * C; v8.ldo = C; v8.o_bs = (long long)S * C;
-                v8.out_scale = 1.0f / FP8_QK_SCALE; v8.S = S; v8.C = C; v8.batch = nb; v8.zeros = c->zeros;
+                v8.out_scale = 1.0f / FP8_QK_SCALE;                // (P8's own scale cancels against the row sums, which are sums of P8)
+                v8.S = S; v8.C = C; v8.batch = nb; v8.zeros = c->zeros;
                 if (c->profiling) {
                     vt_context::ProfRec r0, r1;
                     r0.e0 = c->next_event(); r0.e1 = c->next_event(); r1.e0 = r0.e1; r1.e1 = c->next_event();
@@ -717,6 +720,8 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
                 }
                 continue;
             }
+            k.mode = 1; k.rowout = shift; k.gate = gate; k.gate_expect = 1;
+            HIPCK(c, vt_launch_attn_qk(k, s), "attn row max");
             k.mode = 2; k.P = sc.probs; k.ldp = lp; k.p_bs = (long long)S * lp; k.rowin = shift; k.rowout = rinv; k.gate = nullptr;
             frag_pv = c->attn_pv_kernel && vt_attn_pv_supported(S, C);
             if (frag_pv) { k.p_frag = 1; k.p_bs = vt_attn_pt_elems(S); }

@@ -107,6 +107,8 @@ struct AttnQk8Args {
     float* rowout;                                        // four segment sums per row, [4][split_stride] of [batch][row_bs]
     long long row_bs, split_stride;
     float alpha;                                          // scale applied to the e4m3 dot product (1 / (sqrt(C) * qscale * kscale))
+    float pscale_log2;                                    // mode 3: P8 = e4m3(2^pscale_log2 * exp(alpha q8.k8 - rowin))
+    int mode;                                             // 1: rowout[batch][row_bs] = row maxima of alpha q8.k8, no P; 3: P8 + segment sums
     int batch, nsplit;
     const void* zeros;
 };
