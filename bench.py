@@ -188,6 +188,7 @@ def main():
     vae = load_diffusers_vae_from_config(get_diffusers_vae_config())
     vae.load_state_dict(synth.synth_state_dict(synth.encoder_manifest(), seed=0), strict=False)
     vae_model = DiffusersVAEWrapper(vae).to(dev).eval()
+    vae_model.check_finite = False          # no host synchronisation inside the timed steps: the status word is read once after them
     dec = create_attention_decoder(16, a.height // 8, a.width // 8, a.tags,
                                    {"use_spatial_attention": True, "use_self_attention": True,
                                     "use_cross_attention": False, "attention_heads": 8})

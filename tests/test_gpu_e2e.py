@@ -291,10 +291,14 @@ def test_fp16_overflow_trips_the_status_word_and_fp32_storage_matches_oracle():
     ref = encoder_ref.vae_wrapper_encode(sd, x)
     assert encoder_ref.encoder_moments(sd, x, taps=(t := {})) is not None and t["conv_in"].abs().max() > 65504
     assert m.status() == 0
+    with pytest.raises(FloatingPointError):                    # the reference-shaped wrapper checks by default: finite latents or an exception
+        w.encode(x.cuda())
+    assert m.status() == 0                                     # (the check read and cleared the word)
+    w.check_finite = False                                     # callers that poll the word themselves
     lat = w.encode(x.cuda())
     assert m.status() == 1 and m.status() == 0                 # sticky until read, cleared by the read
     assert not torch.isfinite(lat).all()
-    m.check_finite = True
+    m.check_finite = True                                      # the same switch on the diffusers-shaped object
     with pytest.raises(FloatingPointError):
         w.encode(x.cuda())
     m.set_fp32_residual(True)
@@ -316,6 +320,7 @@ def test_fp8_saturation_trips_its_own_status_bit():
     m = load_diffusers_vae_from_config(get_diffusers_vae_config())
     m.load_state_dict(sd, strict=False)
     w = DiffusersVAEWrapper(m).to("cuda").eval()
+    w.check_finite = False                                     # this test reads the word itself
     x = synth.synth_images(2, 128, 96, seed=5).cuda()
     ctx = m._context()
     lat = w.encode(x)

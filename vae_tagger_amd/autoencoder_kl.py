@@ -102,14 +102,18 @@ class AutoencoderKL(HipModule):
         ws, ptr = workspace(x.device, need)
         ctx.call("vt_encode", vp(x), B, H, W, mode, vp(out), ctypes.c_void_p(ptr), need, stream_ptr(x.device))
         if self.check_finite:
-            st = self.status()
-            if st & _lib.VT_STATUS_NONFINITE:
-                raise FloatingPointError("non-finite activations in the encoder: the fp16 residual-stream storage overflowed "
-                                         "(set_fp32_residual() stores it as fp32) or the checkpoint holds inf / NaN")
-            if st & _lib.VT_STATUS_FP8_SATURATED:
-                raise FloatingPointError("fp8 mode: activations exceeded the e4m3 range and were clamped "
-                                         "(vt_set_flag(ctx, 11, 0) returns to the bf16 path)")
+            self.raise_on_status()
         return out
+
+    def raise_on_status(self):
+        """Read (and clear) the sticky health word -- synchronises -- and raise what it says."""
+        st = self.status()
+        if st & _lib.VT_STATUS_NONFINITE:
+            raise FloatingPointError("non-finite activations in the encoder: the fp16 residual-stream storage overflowed "
+                                     "(set_fp32_residual() stores it as fp32) or the input / checkpoint holds inf / NaN")
+        if st & _lib.VT_STATUS_FP8_SATURATED:
+            raise FloatingPointError("fp8 mode: activations exceeded the e4m3 range and were clamped "
+                                     "(vt_set_flag(ctx, 11, 0) returns to the bf16 path)")
 
     # encode() never synchronises the host, so an overflow of the fp16 residual-stream storage cannot raise from it by
     # itself: the library keeps a sticky device-side status word instead (vt_status).  Callers check it where they

@@ -68,6 +68,12 @@ def load_diffusers_vae_from_pretrained(model_name_or_path, subfolder=None):
 
 
 class DiffusersVAEWrapper(torch.nn.Module):
+    # The reference's `vae_model.encode(x)` either returns finite latents or raises.  The HIP encoder never synchronises the host, so an
+    # overflow of its fp16 residual-stream storage (or an e4m3 clamp in fp8 mode) only raises a sticky device word; this wrapper -- the
+    # object the reference's callers hold -- reads it after every encode (one 4-byte copy + a stream synchronise) and raises.  Callers
+    # that poll the word themselves where they synchronise anyway (the CLIs, EncodeTagPipeline, bench.py) switch it off.
+    check_finite = True
+
     def __init__(self, vae_model):
         super().__init__()
         self.vae = vae_model
@@ -78,7 +84,10 @@ class DiffusersVAEWrapper(torch.nn.Module):
     def encode(self, x):
         if isinstance(self.vae, AutoencoderKL):
             # fused: conv_out epilogue writes mode()*scaling_factor + shift_factor directly
-            return self.vae.encode_mode_scaled(x)
+            latent = self.vae.encode_mode_scaled(x)
+            if self.check_finite and not self.vae.check_finite:
+                self.vae.raise_on_status()
+            return latent
         posterior = self.vae.encode(x).latent_dist
         latent = posterior.mode()
         if getattr(self.vae.config, "scaling_factor", None) is not None:

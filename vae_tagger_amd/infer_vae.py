@@ -36,6 +36,7 @@ def infer_and_save_latents(args):
     device = "cuda"
     print(f"Using device: {device}")
     vae_model = load_vae(args, device)
+    vae_model.check_finite = False          # this loop polls the status word itself (and redoes a batch with fp32 storage)
     transform = get_image_transform(args.resolution)
     if not os.path.exists(args.image_path):
         raise FileNotFoundError(f"图像路径未找到: {args.image_path}")
