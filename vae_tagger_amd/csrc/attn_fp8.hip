@@ -10,6 +10,8 @@
 //     4 (m & 3) + (r & 3) of the 128-key block: the accumulators of lane (q4, .) over the tile's eight MFMA row tiles are then 32
 //     CONSECUTIVE keys 32 q4 .. 32 q4 + 31 -- exactly its B-operand fragment of P.V's k-step over that block, and v^T needs no
 //     permutation at all;
+//   * the exponent shift may be a SAMPLED row maximum (every 8th key tile: 0.2 ms instead of 1.5 ms per step); the numerator sweep raises a
+//     flag when a numerator exceeds e4m3's 448 and the launches gated on that flag redo the group with the exact maximum;
 //   * P8 of (32-query slab, 128-key block) = four 1-KB pieces (query tile qb, key half): 4 KB contiguous per wave and block, 2304 B
 //     between slabs against HBM channel conflicts (as attn_qk.hip); P traffic halves against bf16 (4.3 -> 2.1 GB per 8 images);
 //   * P.V: v8^T tile = 256 channels x 128 keys = 32 KB (the bf16 kernel's bytes, twice its keys); its two ds_read_b128 per fragment
@@ -48,6 +50,7 @@ __device__ __forceinline__ i32x8 cat8(i32x4 lo, i32x4 hi) { return i32x8{lo[0], 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 key tiles
+    if (a.gate && *a.gate != a.gate_expect) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -104,9 +107,12 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
 #pragma unroll
         for (int h = 0; h < 2; ++h) kbase[p][h] = fr * KROWB + ((((8 * p + 2 * fq + h) ^ fr) & 15) << 4);
 
-    f32x4 acc[8][2];
+    // A 128-key tile is worked off in two HALVES of four row tiles (64 keys x 32 queries = 32 accumulator registers): with all eight row
+    // tiles in flight the kernel sat at 255 VGPRs and any further state -- the overflow watch below -- spilled ~100 of them.
+    f32x4 acc[4][2];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     i32x4 hold[2][2];                                      // P8 pieces of the tile: [query tile][key half]
+    float vmax = 0.f;                                      // MODE 3: largest numerator before the clamp (the shift may be a SAMPLED maximum)
 
     auto store_held = [&](int kt_prev) __attribute__((always_inline)) {
         if (row0 < a.S) {
@@ -118,28 +124,30 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
                     __builtin_nontemporal_store(hold[j][h], (i32x4*)(dst + (j * 2 + (h ^ (fq & 1))) * 1024));
         }
     };
-    auto epilogue_t = [&](int kt, auto full_tag) __attribute__((always_inline)) {
+    // scores of half h of tile kt (in acc) -> running row value / P8 piece hold[.][h]
+    auto epilogue_half = [&](int kt, int h /* compile-time at every call */, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const int key0 = kt * KT + 32 * fq;
+        const int key0 = kt * KT + 32 * fq + 16 * h;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
+            for (int mm = 0; mm < 4; ++mm) {
                 if constexpr (MODE == 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (FULL || key0 + 16 * (m >> 2) + 4 * (m & 3) + r < a.S) rv[j] = fmaxf(rv[j], acc[m][j][r] * a.alpha);
+                        if (FULL || key0 + 4 * mm + r < a.S) rv[j] = fmaxf(rv[j], acc[mm][j][r] * a.alpha);
                     continue;
                 }
                 float e[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool real = FULL || key0 + 16 * (m >> 2) + 4 * (m & 3) + r < a.S;
-                    float v = __builtin_amdgcn_exp2f(fmaf(acc[m][j][r], alpha2, -sh2[j]));
+                    const bool real = FULL || key0 + 4 * mm + r < a.S;
+                    float v = __builtin_amdgcn_exp2f(fmaf(acc[mm][j][r], alpha2, -sh2[j]));
                     if (!real) v = 0.f;
+                    vmax = fmaxf(vmax, v);
                     e[r] = fminf(v, 448.f);
                 }
-                int w = hold[j][m >> 2][m & 3];
+                int w = hold[j][h][mm];
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], w, false);
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w, true);
                 // the row sum is taken over the ROUNDED numerators (what P.V multiplies): the weights of a row then sum to one exactly, and a
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
                 const f32x2 d0 = __builtin_amdgcn_cvt_pk_f32_fp8(w, false), d1 = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
                 rv[j] += (d0[0] + d0[1]) + (d1[0] + d1[1]);
-                hold[j][m >> 2][m & 3] = w;
+                hold[j][h][mm] = w;
             }
         }
     };
@@ -165,65 +173,81 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
             rv[j] = 0.f;
         }
     };
-    auto epilogue = [&](int kt) __attribute__((always_inline)) {
-        if (kt * KT + KT <= a.S) epilogue_t(kt, std::true_type{});
-        else epilogue_t(kt, std::false_type{});
+    auto epilogue = [&](int kt, int h) __attribute__((always_inline)) {
+        if (kt * KT + KT <= a.S) epilogue_half(kt, h, std::true_type{});
+        else epilogue_half(kt, h, std::false_type{});
         if constexpr (MODE == 3) {
+            if (h == 1) {
 #pragma unroll
-            for (int seg = 0; seg < 4; ++seg)
-                if (kt + 1 == segb[seg + 1] && segb[seg + 1] > segb[seg]) write_segment(seg, false);
+                for (int seg = 0; seg < 4; ++seg)
+                    if (kt + 1 == segb[seg + 1] && segb[seg + 1] > segb[seg]) write_segment(seg, false);
+            }
         }
     };
 
-    // waves w and w + 4 share a SIMD and run their DMA issue / epilogue on opposite sides of the MFMA block (attn_qk.hip)
+    // Waves w and w + 4 share a SIMD.  Per barrier interval the first four run [MFMAs h0][epilogue h0][MFMAs h1][DMA of the next tile]
+    // [epilogue h1 + stores], the other four [DMA][epilogue h1 + stores of the PREVIOUS tile][MFMAs h0][epilogue h0][MFMAs h1] -- their
+    // second half's accumulators wait across the barrier -- so that one wave's DMA issue, exp / convert / store work runs beside its
+    // partner's MFMAs (attn_qk.hip), now in four alternating phases instead of two.
+    // The wait in front of the barrier is COUNTED (vmcnt(4): the wave's four P8 stores are always younger than its DMA pieces).
     const bool late = (wave & 4) != 0;
     const int seg0 = ksp * (4 / nsplit), seg1 = (ksp + 1) * (4 / nsplit);
     const int kt0 = MODE == 3 ? segb[seg0] : 0, nkt = MODE == 3 ? segb[seg1] : nkt_all;
-    const bool counted = MODE == 3 && row0 < a.S;          // this wave issues exactly 4 stores per epilogue
+    const bool counted = MODE == 3 && row0 < a.S;          // this wave issues exactly 4 stores per tile
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h) hold[j][h] = i32x4{0, 0, 0, 0};
-    if (kt0 < nkt) stage(kt0, kt0 & 1);
-    for (int kt = kt0; kt < nkt; ++kt) {
-        if (counted && kt - kt0 > (late ? 1 : 0)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // MODE 1 may sweep every kstep-th key tile only (a sampled maximum: see run_attention); the two LDS buffers alternate per iteration
+    const int kstep = (MODE == 1 && a.kstride > 1) ? a.kstride : 1;
+    int it = 0;
+    if (kt0 < nkt) stage(kt0, 0);
+    for (int kt = kt0; kt < nkt; kt += kstep, ++it) {
+        if (counted && it > (late ? 1 : 0)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (late) {
-            if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
-            if (kt > kt0) { epilogue(kt - 1); if (MODE == 3) store_held(kt - 1); }
+            if (kt + kstep < nkt) stage(kt + kstep, (it + 1) & 1);
+            if (it > 0) { epilogue(kt - kstep, 1); if (MODE == 3) store_held(kt - kstep); }
         }
-        const char* ks_base = smem + (kt & 1) * KBUF;
+        const char* ks_base = smem + (it & 1) * KBUF;
         // key fragments (32 B per lane = two ds_read_b128) through a ring of register sets, read AHEAD positions before their MFMAs
         constexpr int AHEAD = 3, RING = 4;
-        i32x8 kf[RING];
-        auto frag = [&](int idx) __attribute__((always_inline)) -> i32x8 {
-            const int ks = idx >> 3, m = idx & 7;
-            const char* p = ks_base + (ks >> 1) * 256 + m * 16 * KROWB;
-            return cat8(*(const i32x4*)(p + kbase[ks & 1][0]), *(const i32x4*)(p + kbase[ks & 1][1]));
+        auto half = [&](int h /* compile-time */) __attribute__((always_inline)) {
+            i32x8 kf[RING];
+            auto frag = [&](int idx) __attribute__((always_inline)) -> i32x8 {
+                const int ks = idx >> 2, m = 4 * h + (idx & 3);
+                const char* p = ks_base + (ks >> 1) * 256 + m * 16 * KROWB;
+                return cat8(*(const i32x4*)(p + kbase[ks & 1][0]), *(const i32x4*)(p + kbase[ks & 1][1]));
+            };
+#pragma unroll
+            for (int p = 0; p < AHEAD; ++p) kf[p] = frag(p);
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) {
+                if (idx + AHEAD < 16) kf[(idx + AHEAD) % RING] = frag(idx + AHEAD);
+                const int ks = idx >> 2, mm = idx & 3;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mm][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kf[idx % RING], qf[j][ks], ks == 0 ? zero4 : acc[mm][j], 0, 0, 0, 127, 0, 127);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
-#pragma unroll
-        for (int p = 0; p < AHEAD; ++p) kf[p] = frag(p);
-#pragma unroll
-        for (int idx = 0; idx < 32; ++idx) {
-            if (idx + AHEAD < 32) kf[(idx + AHEAD) % RING] = frag(idx + AHEAD);
-            const int ks = idx >> 3, m = idx & 7;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[m][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kf[idx % RING], qf[j][ks], ks == 0 ? zero4 : acc[m][j], 0, 0, 0, 127, 0, 127);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        half(0);
+        epilogue(kt, 0);
+        half(1);
         if (!late) {
-            if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
-            epilogue(kt);
+            if (kt + kstep < nkt) stage(kt + kstep, (it + 1) & 1);
+            epilogue(kt, 1);
             if (MODE == 3) store_held(kt);
         }
     }
     if (nkt > kt0 && late) {
-        epilogue(nkt - 1);
-        if (MODE == 3) store_held(nkt - 1);
+        const int kl = kt0 + ((nkt - 1 - kt0) / kstep) * kstep;       // the last tile swept
+        epilogue(kl, 1);
+        if (MODE == 3) store_held(kl);
     }
+    if (MODE == 3 && a.flag && __any(vmax > 448.f) && lane == 0) atomicOr(a.flag, 1);
     if constexpr (MODE == 3) {
 #pragma unroll
         for (int seg = 0; seg < 4; ++seg)
@@ -251,6 +275,7 @@ __global__ __launch_bounds__(512, 2) void attn_pv_fp8_kernel(const AttnPv8Args a
     constexpr int NCT = CB / 16;
     constexpr int NCP = D / CB;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 v^T tiles
+    if (a.gate && *a.gate != a.gate_expect) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -382,6 +407,7 @@ hipError_t vt_launch_attn_qk_fp8(const AttnQk8Args& a, hipStream_t s) {
     if ((a.ldq % 16) || (a.qk_bs % 16) || a.row_bs < a.S) return hipErrorInvalidValue;
     if (a.mode == 3 && (!a.P8 || !a.rowin || (a.p_bs % 16) || a.p_bs < vt_attn_p8_bytes(a.S))) return hipErrorInvalidValue;
     if (a.mode == 1 && a.nsplit > 1) return hipErrorInvalidValue;
+    if (a.kstride < 0 || (a.mode == 3 && a.kstride > 1)) return hipErrorInvalidValue;
     if ((long long)a.S * a.ldq >= (1LL << 31)) return hipErrorInvalidValue;
     if (a.nsplit > 1 && a.nsplit != 2 && a.nsplit != 4) return hipErrorInvalidValue;
     if (a.mode == 3 && a.split_stride < (long long)a.batch * a.row_bs) return hipErrorInvalidValue;

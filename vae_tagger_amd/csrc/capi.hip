@@ -579,6 +579,7 @@ size_t attn_pitch8(int S) {
 }
 constexpr float FP8_QK_SCALE = 8.0f;       // q8 | k8 = e4m3(8 q | 8 k), v8 = e4m3(8 v): |values| up to 56 before saturation (status bit 1)
 constexpr float FP8_P_SCALE_LOG2 = 8.0f;   // P8 = e4m3(256 exp(s - max)): numerators <= 256 < 448, e4m3's normal range reaches 6e-5 of the row maximum
+constexpr float FP8_P_SCALE_SAMPLED_LOG2 = 5.0f;   // ... e4m3(32 exp(s - sampled max)): 2.6 nats of head room above the sampled maximum, 5e-4 below
 // Probabilities (and, on the three-pass path, scores) are materialised for `group` images at a time (one batched launch
 // each for Q.K^T and P.V): as many images as fit a 9.25 GiB budget (1.13 GiB per image at S = 16384), in equal launches.
 int attn_group(int B, int S) {
@@ -651,7 +652,8 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
     const int mode = c->attn_mode;                  // 0: exponent shift from operand norms, exact row maximum if flagged;
                                                     // 1: always the exact row maximum; 2: scores -> softmax pass -> P
     if (f8) {
-        // (q8 | k8 come out of the row-norms pass; the norms themselves are not used: the fp8 path takes the exact row maximum)
+        HIPCK(c, hipMemsetAsync(sc.flags, 0, (size_t)((B + sc.group - 1) / sc.group) * 4, s), "attn flags");
+        // (q8 | k8 come out of the row-norms pass; the norms themselves are not used: the fp8 path takes a sampled / the exact row maximum)
         HIPCK(c, vt_launch_attn_row_norms_fp8(sc.qk, (long long)B * S, C, FP8_QK_SCALE, sc.qk8, sc.qn, sc.kn, sc.sd, c->status, s), "attn q|k -> e4m3");
     } else if (mode == 0) {
         HIPCK(c, hipMemsetAsync(sc.flags, 0, (size_t)((B + sc.group - 1) / sc.group) * 4, s), "attn flags");
@@ -690,32 +692,53 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
                 q8.qk8 = sc.qk8 + (long long)b0 * S * 2 * C; q8.ldq = 2 * C; q8.qk_bs = (long long)S * 2 * C; q8.S = S; q8.C = C;
                 q8.P8 = (unsigned char*)sc.probs; q8.p_bs = vt_attn_p8_bytes(S); q8.rowin = shift; q8.rowout = sc.part;
                 q8.row_bs = S; q8.split_stride = (long long)nb * S; q8.alpha = scale / (FP8_QK_SCALE * FP8_QK_SCALE); q8.batch = nb; q8.zeros = c->zeros;
-                q8.pscale_log2 = FP8_P_SCALE_LOG2;
-                q8.mode = 1; q8.rowout = shift; q8.nsplit = 1;
-                HIPCK(c, vt_launch_attn_qk_fp8(q8, s), "attn row max fp8");
-                q8.mode = 3; q8.rowout = sc.part;
                 const int qblocks = nb * ((S + 255) / 256), ktiles = (S + 127) / 128;
-                q8.nsplit = qblocks > 128 ? 1 : qblocks > 64 ? 2 : 4;
-                while (q8.nsplit > 1 && ktiles / q8.nsplit < 4) q8.nsplit >>= 1;
+                const int nsplit8 = [&] { int n = qblocks > 128 ? 1 : qblocks > 64 ? 2 : 4; while (n > 1 && ktiles / n < 4) n >>= 1; return n; }();
+                // The shift must be (close to) the row maximum: e4m3's range is too short for the bound from operand norms.  A full first
+                // sweep costs 1.5 ms per step; instead the first sweep takes every kstride-th key tile -- a SAMPLED maximum m <= max -- and the
+                // numerators are stored as e4m3(32 exp(s - m)): exact while the true maximum is within ln(448 / 32) = 2.6 of the sampled one
+                // (thousands of keys per row: always, on the weights seen so far).  A numerator beyond 448 raises the group's flag, and the two
+                // launches gated on it redo the group with the exact maximum and e4m3(256 x) -- no host round trip.  vt_set_flag(7, 1):
+                // always exact.
+                const int kstride = (mode == 1) ? 1 : ktiles >= 64 ? 8 : ktiles >= 16 ? 4 : 1;
+                int* flag8 = sc.flags + b0 / sc.group;
+                q8.mode = 1; q8.rowout = shift; q8.nsplit = 1; q8.kstride = kstride;
+                HIPCK(c, vt_launch_attn_qk_fp8(q8, s), "attn row max fp8");
+                AttnQk8Args redo = q8;
+                q8.mode = 3; q8.rowout = sc.part; q8.kstride = 0; q8.nsplit = nsplit8;
+                q8.pscale_log2 = kstride > 1 ? FP8_P_SCALE_SAMPLED_LOG2 : FP8_P_SCALE_LOG2;
                 AttnPv8Args v8{};
                 v8.P8 = q8.P8; v8.p_bs = q8.p_bs; v8.vt8 = sc.vt8 + (long long)b0 * C * ld8; v8.ldv = ld8; v8.vt_bs = (long long)C * ld8; v8.kext = kext8;
                 v8.rsum = sc.part; v8.row_bs = S; v8.split_stride = (long long)nb * S; v8.o = sc.o + (long long)b0 * S * C; v8.ldo = C; v8.o_bs = (long long)S * C;
                 v8.out_scale = 1.0f / FP8_QK_SCALE;                // (P8's own scale cancels against the row sums, which are sums of P8)
                 v8.S = S; v8.C = C; v8.batch = nb; v8.zeros = c->zeros;
+                q8.flag = kstride > 1 ? flag8 : nullptr;
+                auto redo_exact = [&]() -> int {             // both launches are no-ops unless the numerator sweep met a value beyond 448
+                    if (kstride <= 1) return VT_OK;
+                    redo.kstride = 0; redo.gate = flag8; redo.gate_expect = 1;
+                    HIPCK(c, vt_launch_attn_qk_fp8(redo, s), "attn row max fp8 (exact)");
+                    redo.mode = 3; redo.rowout = sc.part; redo.nsplit = nsplit8; redo.pscale_log2 = FP8_P_SCALE_LOG2; redo.flag = nullptr;
+                    HIPCK(c, vt_launch_attn_qk_fp8(redo, s), "attn exp scores fp8 (exact)");
+                    return VT_OK;
+                };
+                int rr;
                 if (c->profiling) {
                     vt_context::ProfRec r0, r1;
-                    r0.e0 = c->next_event(); r0.e1 = c->next_event(); r1.e0 = r0.e1; r1.e1 = c->next_event();
-                    if (!r0.e0 || !r0.e1 || !r1.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+                    r0.e0 = c->next_event(); r0.e1 = c->next_event(); r1.e0 = c->next_event(); r1.e1 = c->next_event();
+                    if (!r0.e0 || !r0.e1 || !r1.e0 || !r1.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
                     r0.flops = r1.flops = 2.0 * nb * (double)S * S * C;
                     r0.cfg = VT_PROF_ATTN_QK8; r1.cfg = VT_PROF_ATTN_PV8;
                     HIPCK(c, hipEventRecord(r0.e0, s), "hipEventRecord");
                     HIPCK(c, vt_launch_attn_qk_fp8(q8, s), "attn exp scores fp8");
                     HIPCK(c, hipEventRecord(r0.e1, s), "hipEventRecord");
+                    if ((rr = redo_exact())) return rr;
+                    HIPCK(c, hipEventRecord(r1.e0, s), "hipEventRecord");
                     HIPCK(c, vt_launch_attn_pv_fp8(v8, s), "attn pv fp8");
                     HIPCK(c, hipEventRecord(r1.e1, s), "hipEventRecord");
                     c->prof.push_back(r0); c->prof.push_back(r1);
                 } else {
                     HIPCK(c, vt_launch_attn_qk_fp8(q8, s), "attn exp scores fp8");
+                    if ((rr = redo_exact())) return rr;
                     HIPCK(c, vt_launch_attn_pv_fp8(v8, s), "attn pv fp8");
                 }
                 continue;

@@ -109,6 +109,9 @@ struct AttnQk8Args {
     float alpha;                                          // scale applied to the e4m3 dot product (1 / (sqrt(C) * qscale * kscale))
     float pscale_log2;                                    // mode 3: P8 = e4m3(2^pscale_log2 * exp(alpha q8.k8 - rowin))
     int mode;                                             // 1: rowout[batch][row_bs] = row maxima of alpha q8.k8, no P; 3: P8 + segment sums
+    int kstride;                                          // mode 1: sweep every kstride-th 128-key tile only (0 / 1 = all): a sampled maximum
+    int* flag;                                            // mode 3, optional: bit 0 is raised when a numerator exceeded 448 and was clamped
+    const int* gate; int gate_expect;                     // optional: the launch is a no-op unless *gate == gate_expect
     int batch, nsplit;
     const void* zeros;
 };
@@ -119,6 +122,7 @@ struct AttnPv8Args {
     const float* rsum; long long row_bs, split_stride;
     bf16_t* o; int ldo; long long o_bs;                   // [S][ldo] bf16
     float out_scale;                                      // 1 / vscale
+    const int* gate; int gate_expect;                     // optional: the launch is a no-op unless *gate == gate_expect
     int S, C, batch;
     const void* zeros;
 };
