@@ -133,7 +133,7 @@ def pmc_traffic(kernel, batch, height, width, fp8=False):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (tools/profile_round.sh: separate
     FETCH_SIZE and WRITE_SIZE passes; both in KB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).
     Only valid for the workload the counters were collected on (batch 16 x 1024^2); None otherwise."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02",
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03",
                         f"pmc_traffic_b16_1024_{'fp8' if fp8 else 'bf16'}.json")
     if (batch, height, width) != (16, 1024, 1024) or not os.path.exists(path):
         return None, None
