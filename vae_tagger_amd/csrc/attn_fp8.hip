@@ -17,7 +17,8 @@
 //   * P.V: v8^T tile = 256 channels x 128 keys = 32 KB (the bf16 kernel's bytes, twice its keys); its two ds_read_b128 per fragment
 //     take the chunk pair in an order that depends on the lane quarter (conflict-free under the 8-chunk XOR swizzle), and
 //     Q.K^T stores P8's two key halves of a lane in that same order -- the MFMA only needs A and B to agree.
-// Row sums: four fixed segment sums, as attn_qk.hip (batch-size invariant bits), of the e4m3-ROUNDED numerators.
+// Row sums: of the e4m3-ROUNDED numerators, by the matrix pipe: P.V multiplies P8 with one more row of v^T that holds 1.0 everywhere
+// (an A operand of constants, nothing read), so that a row's weights sum to one exactly and the Q.K^T epilogue carries no sum.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
     f32x4 acc[4][2];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     i32x4 hold[2][2];                                      // P8 pieces of the tile: [query tile][key half]
-    float vmax = 0.f;                                      // MODE 3: largest numerator before the clamp (the shift may be a SAMPLED maximum)
+    unsigned clampw = 0;                                   // MODE 3: bit 7 of a byte set <=> some stored P8 byte is 448 (the shift may be a SAMPLED maximum)
 
     auto store_held = [&](int kt_prev) __attribute__((always_inline)) {
         if (row0 < a.S) {
@@ -144,45 +145,25 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
                     const bool real = FULL || key0 + 4 * mm + r < a.S;
                     float v = __builtin_amdgcn_exp2f(fmaf(acc[mm][j][r], alpha2, -sh2[j]));
                     if (!real) v = 0.f;
-                    vmax = fmaxf(vmax, v);
                     e[r] = fminf(v, 448.f);
                 }
+                // (no row sum here: this epilogue is what bounds the kernel -- ~20 VALU cycles per score against 16 matrix-pipe cycles -- and
+                // P.V gets the sum of the ROUNDED numerators for two extra MFMAs per tile, from an all-ones row of v^T)
                 int w = hold[j][h][mm];
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], w, false);
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w, true);
-                // the row sum is taken over the ROUNDED numerators (what P.V multiplies): the weights of a row then sum to one exactly, and a
-                // row dominated by one key returns that key's v -- with the sum of the unrounded values the e4m3 step of the big numerator
-                // (up to 6 %) went straight into the output
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                const f32x2 d0 = __builtin_amdgcn_cvt_pk_f32_fp8(w, false), d1 = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
-                rv[j] += (d0[0] + d0[1]) + (d1[0] + d1[1]);
+                // a byte of 0x7e = 448: a numerator reached the clamp (values of 432 .. 448 round there too: a rare false alarm costs one
+                // exact redo).  All bytes are <= 0x7e, so +2 per byte carries nothing into its neighbour.
+                clampw |= ((unsigned)w + 0x02020202u) & 0x80808080u;
                 hold[j][h][mm] = w;
             }
         }
     };
     const int nkt_all = (a.S + KT - 1) / KT;
     const int segb[5] = {0, nkt_all / 4, nkt_all / 2, (int)(3LL * nkt_all / 4), nkt_all};
-    auto write_segment = [&](int seg, bool zero) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float v = zero ? 0.f : rv[j];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            const int row = row0 + j * 16 + fr;
-            if (fq == 0 && row < a.S) a.rowout[(long long)seg * a.split_stride + (long long)b * a.row_bs + row] = v;
-            rv[j] = 0.f;
-        }
-    };
     auto epilogue = [&](int kt, int h) __attribute__((always_inline)) {
         if (kt * KT + KT <= a.S) epilogue_half(kt, h, std::true_type{});
         else epilogue_half(kt, h, std::false_type{});
-        if constexpr (MODE == 3) {
-            if (h == 1) {
-#pragma unroll
-                for (int seg = 0; seg < 4; ++seg)
-                    if (kt + 1 == segb[seg + 1] && segb[seg + 1] > segb[seg]) write_segment(seg, false);
-            }
-        }
     };
 
     // Waves w and w + 4 share a SIMD.  Per barrier interval the first four run [MFMAs h0][epilogue h0][MFMAs h1][DMA of the next tile]
@@ -247,13 +228,8 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
         epilogue(kl, 1);
         if (MODE == 3) store_held(kl);
     }
-    if (MODE == 3 && a.flag && __any(vmax > 448.f) && lane == 0) atomicOr(a.flag, 1);
-    if constexpr (MODE == 3) {
-#pragma unroll
-        for (int seg = 0; seg < 4; ++seg)
-            if (seg >= seg0 && seg < seg1 && segb[seg + 1] == segb[seg]) write_segment(seg, true);
-        return;
-    }
+    if (MODE == 3 && a.flag && __any(clampw != 0u) && lane == 0) atomicOr(a.flag, 1);
+    if constexpr (MODE == 3) return;
     // MODE 1: the four fq lanes of a row hold its other keys
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -317,6 +293,9 @@ __global__ __launch_bounds__(512, 2) void attn_pv_fp8_kernel(const AttnPv8Args a
         for (int j = 0; j < 2; ++j) acc[ct][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     i32x8 pf[2], pn[2];
+    // row sums of P8 by the matrix pipe: A = a tile of e4m3 1.0 (0x38), so accs[j][.] of lane (., fr) = sum_k P8[query 16 j + fr][k]
+    const i32x8 ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
+    f32x4 accs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     auto load_p = [&](int kt, i32x8 (&d)[2]) __attribute__((always_inline)) {
         const unsigned char* s = pt + (long long)kt * 4096;
 #pragma unroll
@@ -346,6 +325,8 @@ __global__ __launch_bounds__(512, 2) void attn_pv_fp8_kernel(const AttnPv8Args a
             acc[ct][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[ct % RING], pf[1], acc[ct][1], 0, 0, 0, 127, 0, 127);
             __builtin_amdgcn_sched_barrier(0);
         }
+        accs[0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones8, pf[0], accs[0], 0, 0, 0, 127, 0, 127);
+        accs[1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones8, pf[1], accs[1], 0, 0, 0, 127, 0, 127);
         if (kt + 1 < nkt) { pf[0] = pn[0]; pf[1] = pn[1]; }
     }
     if (!slab_real) return;
@@ -353,8 +334,7 @@ __global__ __launch_bounds__(512, 2) void attn_pv_fp8_kernel(const AttnPv8Args a
     for (int j = 0; j < 2; ++j) {
         const int row = slab * 32 + j * 16 + fr;
         if (row >= a.S) continue;
-        const float* ps = a.rsum + (long long)b * a.row_bs + row;
-        const float rs = a.out_scale / (((ps[0] + ps[a.split_stride]) + ps[2 * a.split_stride]) + ps[3 * a.split_stride]);
+        const float rs = a.out_scale / accs[j][0];
         bf16_t* o = a.o + (long long)b * a.o_bs + (long long)row * a.ldo + cb * CB + 16 * fq;
 #pragma unroll
         for (int G = 0; G < CB / 64; ++G)
@@ -403,14 +383,13 @@ bool vt_attn_fp8_supported(int S, int C) { return C == D && S > 0; }
 long long vt_attn_p8_bytes(int S) { return (long long)((S + 31) / 32) * vt_attn_p8_slab_stride(S); }
 
 hipError_t vt_launch_attn_qk_fp8(const AttnQk8Args& a, hipStream_t s) {
-    if (!a.qk8 || !a.rowout || !a.zeros || a.batch <= 0 || !vt_attn_fp8_supported(a.S, a.C) || (a.mode != 1 && a.mode != 3)) return hipErrorInvalidValue;
+    if (!a.qk8 || (a.mode == 1 && !a.rowout) || !a.zeros || a.batch <= 0 || !vt_attn_fp8_supported(a.S, a.C) || (a.mode != 1 && a.mode != 3)) return hipErrorInvalidValue;
     if ((a.ldq % 16) || (a.qk_bs % 16) || a.row_bs < a.S) return hipErrorInvalidValue;
     if (a.mode == 3 && (!a.P8 || !a.rowin || (a.p_bs % 16) || a.p_bs < vt_attn_p8_bytes(a.S))) return hipErrorInvalidValue;
     if (a.mode == 1 && a.nsplit > 1) return hipErrorInvalidValue;
     if (a.kstride < 0 || (a.mode == 3 && a.kstride > 1)) return hipErrorInvalidValue;
     if ((long long)a.S * a.ldq >= (1LL << 31)) return hipErrorInvalidValue;
     if (a.nsplit > 1 && a.nsplit != 2 && a.nsplit != 4) return hipErrorInvalidValue;
-    if (a.mode == 3 && a.split_stride < (long long)a.batch * a.row_bs) return hipErrorInvalidValue;
     const long long nblk = (long long)((a.S + QB - 1) / QB) * a.batch * (a.nsplit > 1 ? a.nsplit : 1);
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> attr_done{0};
@@ -425,9 +404,9 @@ hipError_t vt_launch_attn_qk_fp8(const AttnQk8Args& a, hipStream_t s) {
 }
 
 hipError_t vt_launch_attn_pv_fp8(const AttnPv8Args& a, hipStream_t s) {
-    if (!a.P8 || !a.vt8 || !a.rsum || !a.o || !a.zeros || a.batch <= 0 || !vt_attn_fp8_supported(a.S, a.C)) return hipErrorInvalidValue;
-    if ((a.ldv % 16) || (a.vt_bs % 16) || (a.ldo % 8) || (a.o_bs % 8) || (a.p_bs % 16) || a.row_bs < a.S || (a.kext % 16) || a.kext > a.ldv) return hipErrorInvalidValue;
-    if ((long long)a.C * a.ldv >= (1LL << 31) || a.split_stride < (long long)a.batch * a.row_bs) return hipErrorInvalidValue;
+    if (!a.P8 || !a.vt8 || !a.o || !a.zeros || a.batch <= 0 || !vt_attn_fp8_supported(a.S, a.C)) return hipErrorInvalidValue;
+    if ((a.ldv % 16) || (a.vt_bs % 16) || (a.ldo % 8) || (a.o_bs % 8) || (a.p_bs % 16) || (a.kext % 16) || a.kext > a.ldv) return hipErrorInvalidValue;
+    if ((long long)a.C * a.ldv >= (1LL << 31)) return hipErrorInvalidValue;
     const long long qblk = (long long)((a.S + QB - 1) / QB) * a.batch;
     const bool narrow = qblk * 2 < 192;
     const long long nblk = qblk * (narrow ? 4 : 2);

@@ -687,11 +687,10 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
             if (f8) {
                 // fp8 mode: both contractions on e4m3 operands.  The exponent shift is the exact row maximum of the e4m3 scores (a first
                 // sweep of the same kernel without exp / convert / store): numerators <= 1, stored as e4m3(256 x)
-                if ((size_t)4 * nb * S > sc.group * attn_slots_bound(S) * (size_t)S) return c->fail(VT_ERR_WORKSPACE, "attention: segment sums exceed the scratch");
                 AttnQk8Args q8{};
                 q8.qk8 = sc.qk8 + (long long)b0 * S * 2 * C; q8.ldq = 2 * C; q8.qk_bs = (long long)S * 2 * C; q8.S = S; q8.C = C;
-                q8.P8 = (unsigned char*)sc.probs; q8.p_bs = vt_attn_p8_bytes(S); q8.rowin = shift; q8.rowout = sc.part;
-                q8.row_bs = S; q8.split_stride = (long long)nb * S; q8.alpha = scale / (FP8_QK_SCALE * FP8_QK_SCALE); q8.batch = nb; q8.zeros = c->zeros;
+                q8.P8 = (unsigned char*)sc.probs; q8.p_bs = vt_attn_p8_bytes(S); q8.rowin = shift;
+                q8.row_bs = S; q8.alpha = scale / (FP8_QK_SCALE * FP8_QK_SCALE); q8.batch = nb; q8.zeros = c->zeros;
                 const int qblocks = nb * ((S + 255) / 256), ktiles = (S + 127) / 128;
                 const int nsplit8 = [&] { int n = qblocks > 128 ? 1 : qblocks > 64 ? 2 : 4; while (n > 1 && ktiles / n < 4) n >>= 1; return n; }();
                 // The shift must be (close to) the row maximum: e4m3's range is too short for the bound from operand norms.  A full first
@@ -705,11 +704,11 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
                 q8.mode = 1; q8.rowout = shift; q8.nsplit = 1; q8.kstride = kstride;
                 HIPCK(c, vt_launch_attn_qk_fp8(q8, s), "attn row max fp8");
                 AttnQk8Args redo = q8;
-                q8.mode = 3; q8.rowout = sc.part; q8.kstride = 0; q8.nsplit = nsplit8;
+                q8.mode = 3; q8.rowout = nullptr; q8.kstride = 0; q8.nsplit = nsplit8;
                 q8.pscale_log2 = kstride > 1 ? FP8_P_SCALE_SAMPLED_LOG2 : FP8_P_SCALE_LOG2;
                 AttnPv8Args v8{};
                 v8.P8 = q8.P8; v8.p_bs = q8.p_bs; v8.vt8 = sc.vt8 + (long long)b0 * C * ld8; v8.ldv = ld8; v8.vt_bs = (long long)C * ld8; v8.kext = kext8;
-                v8.rsum = sc.part; v8.row_bs = S; v8.split_stride = (long long)nb * S; v8.o = sc.o + (long long)b0 * S * C; v8.ldo = C; v8.o_bs = (long long)S * C;
+                v8.o = sc.o + (long long)b0 * S * C; v8.ldo = C; v8.o_bs = (long long)S * C;
                 v8.out_scale = 1.0f / FP8_QK_SCALE;                // (P8's own scale cancels against the row sums, which are sums of P8)
                 v8.S = S; v8.C = C; v8.batch = nb; v8.zeros = c->zeros;
                 q8.flag = kstride > 1 ? flag8 : nullptr;
@@ -717,7 +716,7 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
                     if (kstride <= 1) return VT_OK;
                     redo.kstride = 0; redo.gate = flag8; redo.gate_expect = 1;
                     HIPCK(c, vt_launch_attn_qk_fp8(redo, s), "attn row max fp8 (exact)");
-                    redo.mode = 3; redo.rowout = sc.part; redo.nsplit = nsplit8; redo.pscale_log2 = FP8_P_SCALE_LOG2; redo.flag = nullptr;
+                    redo.mode = 3; redo.rowout = nullptr; redo.nsplit = nsplit8; redo.pscale_log2 = FP8_P_SCALE_LOG2; redo.flag = nullptr;
                     HIPCK(c, vt_launch_attn_qk_fp8(redo, s), "attn exp scores fp8 (exact)");
                     return VT_OK;
                 };

@@ -104,11 +104,11 @@ struct AttnQk8Args {
     int S, C;
     unsigned char* P8; long long p_bs;                    // fragment-ordered e4m3 P: vt_attn_p8_bytes(S) per image
     const float* rowin;                                   // per-row exponent shift [batch][row_bs]
-    float* rowout;                                        // four segment sums per row, [4][split_stride] of [batch][row_bs]
-    long long row_bs, split_stride;
+    float* rowout;                                        // mode 1: row maxima [batch][row_bs]
+    long long row_bs;
     float alpha;                                          // scale applied to the e4m3 dot product (1 / (sqrt(C) * qscale * kscale))
     float pscale_log2;                                    // mode 3: P8 = e4m3(2^pscale_log2 * exp(alpha q8.k8 - rowin))
-    int mode;                                             // 1: rowout[batch][row_bs] = row maxima of alpha q8.k8, no P; 3: P8 + segment sums
+    int mode;                                             // 1: rowout[batch][row_bs] = row maxima of alpha q8.k8, no P; 3: P8 (P.V takes the row sums itself)
     int kstride;                                          // mode 1: sweep every kstride-th 128-key tile only (0 / 1 = all): a sampled maximum
     int* flag;                                            // mode 3, optional: bit 0 is raised when a numerator exceeded 448 and was clamped
     const int* gate; int gate_expect;                     // optional: the launch is a no-op unless *gate == gate_expect
@@ -119,7 +119,6 @@ struct AttnPv8Args {
     const unsigned char* P8; long long p_bs;
     const unsigned char* vt8; int ldv; long long vt_bs;   // v^T [C][ldv] e4m3 (keys contiguous); keys >= kext are not read (zero page)
     int kext;
-    const float* rsum; long long row_bs, split_stride;
     bf16_t* o; int ldo; long long o_bs;                   // [S][ldo] bf16
     float out_scale;                                      // 1 / vscale
     const int* gate; int gate_expect;                     // optional: the launch is a no-op unless *gate == gate_expect
