@@ -296,20 +296,40 @@ def test_fp8_mfma_block_sum_keeps_a_bounded_window_below_its_largest_product(ops
                 assert v == exact, (j, exact, v)             # products within 2^-13 of the largest are kept exactly
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 128, 34, 50), (1, 256, 16, 16), (1, 512, 18, 22)])
-def test_fp8_stride2_conv_matches_torch_on_the_same_quantised_operands(ops, B, C, H, W):
-    """Downsample2D's conv (pad (0,1,0,1), stride 2) on e4m3 operands: conv_gemm_kernel<..., F8> with
-    v_mfma_scale_f32_16x16x128_f8f6f4 (the fp8 mode's stride-2 convs).  The un-normalised residual stream is quantised as e4m3(x)."""
-    x = 3.0 * _rand((B, C, H, W), 5)
-    w = _rand((C, C, 3, 3), 6, (C * 9) ** -0.5)
-    b = _rand((C,), 7, 0.1)
+@pytest.mark.parametrize("s2_halo", [1, 0], ids=["phase_plane", "generic"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 128, 34, 50), (1, 256, 256, 16, 16), (1, 512, 512, 18, 22), (1, 128, 256, 70, 133), (2, 64, 128, 64, 64),
+                                            (1, 1024, 128, 17, 65)])
+def test_fp8_stride2_conv_matches_torch_on_the_same_quantised_operands(ops, s2_halo, B, Cin, Cout, H, W):
+    """Downsample2D's conv (pad (0,1,0,1), stride 2) on e4m3 operands, the fp8 mode's stride-2 layers: conv3x3_s2_halo_fp8.hip (phase planes
+    of the input, v_mfma_scale_f32_32x32x64_f8f6f4; ragged 8 x 32 tiles, odd / even sizes, 1-16 channel chunks, 1-4 cout tiles) and, with
+    vt_set_flag(13, 0), conv_gemm_kernel<..., F8>.  The un-normalised residual stream is quantised as e4m3(x)."""
+    x = 3.0 * _rand((B, Cin, H, W), 5)
+    w = _rand((Cout, Cin, 3, 3), 6, (Cin * 9) ** -0.5)
+    b = _rand((Cout,), 7, 0.1)
     sc = w.abs().amax(dim=(1, 2, 3), keepdim=True) / 448.0
     wq = _e4m3(w / sc) * sc
     ref = F.conv2d(F.pad(_e4m3(x), (0, 1, 0, 1)), wq, b, stride=2)
     res = _rand(tuple(ref.shape), 8)
-    got = ops.conv3x3_fp8(x, w, b, residual_nchw=res, stride=2)
+    ops.ctx.call("vt_set_flag", 13, s2_halo)
+    try:
+        got = ops.conv3x3_fp8(x, w, b, residual_nchw=res, stride=2)
+    finally:
+        ops.ctx.call("vt_set_flag", 13, 1)
     assert got.shape == ref.shape
     assert torch.allclose(got, ref + res, rtol=1e-4, atol=2e-3), (got - ref - res).abs().max()
+
+
+def test_fp8_stride2_conv_one_hot_taps(ops):
+    """The fp8 phase-plane kernel with one-hot weights, one tap at a time, on small-integer inputs (exact in e4m3): every tap must read
+    in(2y + ky, 2x + kx) exactly."""
+    Cin = Cout = 128
+    x = (torch.arange(2 * Cin * 19 * 70, dtype=torch.float32).reshape(2, Cin, 19, 70) % 17) - 8.0
+    for tap in range(9):
+        w = torch.zeros(Cout, Cin, 3, 3)
+        w[torch.arange(Cout), torch.arange(Cin), tap // 3, tap % 3] = 1.0
+        ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, stride=2)
+        got = ops.conv3x3_fp8(x, w, stride=2)
+        assert got.shape == ref.shape and torch.equal(got, ref), f"tap {tap}"
 
 
 def test_c_abi_error_paths_return_codes_and_messages(ops):

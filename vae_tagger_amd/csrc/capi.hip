@@ -27,6 +27,7 @@ struct ConvW {
     const bf16_t* wp2 = nullptr;        // stride-2 phase-plane kernel's packing (conv3x3_s2_halo.hip)
     const unsigned char* wp8 = nullptr; const float* mult8 = nullptr;   // fp8 halo kernel: e4m3 weights / per-cout (scale / act_scale)
     const unsigned char* w8g = nullptr; const float* mult8g = nullptr;  // fp8 generic GEMM (stride-2 convs): [cout][tap][cin] e4m3 / per-cout scale (input scale 1)
+    const unsigned char* wp8s2 = nullptr;                                // fp8 stride-2 phase-plane kernel's packing (same scales: mult8g)
 };
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
 struct ResnetW {
@@ -104,6 +105,17 @@ void pack_conv_fp8(const float* w_oihw, int cout, int cin, std::vector<uint8_t>*
         for (int i = 0; i < cin; ++i)
             for (int t = 0; t < 9; ++t)
                 (*wp8)[(((size_t)(i >> 6) * 9 + vt_halo_step_of_tap(t)) * cout + row) * 64 + (i & 63)] = f2e4m3(w_oihw[((size_t)o * cin + i) * 9 + t] / sc);
+    }
+}
+
+// e4m3 packing of a 3x3 conv for conv3x3_s2_halo_fp8.hip: Wp[cin/64][step (vt_s2_step_of_tap)][cout row][64], values w / scale[cout]
+void pack_conv_s2_fp8(const float* w_oihw, int cout, int cin, const float* scale /* per cout */, std::vector<uint8_t>* wp8) {
+    wp8->assign((size_t)cout * 9 * cin, 0);
+    for (int o = 0; o < cout; ++o) {
+        const int row = (o & ~31) + vt_halo_fp8_row_of_cout(o & 31);
+        for (int i = 0; i < cin; ++i)
+            for (int t = 0; t < 9; ++t)
+                (*wp8)[(((size_t)(i >> 6) * 9 + vt_s2_step_of_tap(t)) * cout + row) * 64 + (i & 63)] = f2e4m3(w_oihw[((size_t)o * cin + i) * 9 + t] / scale[o]);
     }
 }
 
@@ -252,6 +264,14 @@ int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, C
         out->w8g = (const unsigned char*)c->upload(g8.data(), g8.size());
         out->mult8g = (const float*)c->upload(mg.data(), mg.size() * 4);
         if (!out->w8g || !out->mult8g) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+        if (stride2 && vt_conv3x3_s2_fp8_supported(cin, cout)) {
+            std::vector<float> sc8(cout);
+            for (int o = 0; o < cout; ++o) sc8[o] = m8[o] * FP8_ACT_SCALE;
+            std::vector<uint8_t> s2p;
+            pack_conv_s2_fp8(w->v.data(), cout, cin, sc8.data(), &s2p);
+            out->wp8s2 = (const unsigned char*)c->upload(s2p.data(), s2p.size());
+            if (!out->wp8s2) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+        }
     }
     return VT_OK;
 }
@@ -447,6 +467,27 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     if (x_fp8 && stride == 2) {
         // stride-2 conv on e4m3 operands: the generic implicit GEMM with the fp8 MFMA (x = e4m3(FP8_RES_SCALE * h))
         if (!w.w8g || w.k != 3 || ss || sc || o16_e4m3) return c->fail(VT_ERR_STATE, "internal: fp8 operands requested for a conv the fp8 GEMM cannot run");
+        if (c->s2_halo && w.wp8s2 && pad == 0 && Hout == Hin / 2 && Wout == Win / 2 && !res16) {
+            Conv3x3S2Fp8Args h{};
+            h.X = (const unsigned char*)x; h.Wp = w.wp8s2; h.mult = w.mult8g; h.bias = w.b; h.res = res32;
+            h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
+            h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
+            if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_s2_fp8_tiles(Hout, Wout); }
+            if (c->profiling) {
+                vt_context::ProfRec r;
+                r.e0 = c->next_event(); r.e1 = c->next_event();
+                if (!r.e0 || !r.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+                r.flops = 2.0 * B * (double)Hout * Wout * w.cout * 9.0 * w.cin;
+                r.cfg = VT_PROF_S2_HALO_FP8;
+                HIPCK(c, hipEventRecord(r.e0, s), "hipEventRecord");
+                HIPCK(c, vt_launch_conv3x3_s2_fp8(h, s), "conv3x3_s2_fp8");
+                HIPCK(c, hipEventRecord(r.e1, s), "hipEventRecord");
+                c->prof.push_back(r);
+            } else {
+                HIPCK(c, vt_launch_conv3x3_s2_fp8(h, s), "conv3x3_s2_fp8");
+            }
+            return VT_OK;
+        }
         ConvGemmArgs a{};
         a.X = (const bf16_t*)x; a.W = (const bf16_t*)w.w8g; a.f8 = 1; a.col_scale = w.mult8g;
         a.bias = w.b; a.res = res32; a.res_f16 = res16; a.out_f32 = o32; a.out_f16 = oh16; a.out_bf16 = o16; a.zeros = c->zeros;
@@ -856,6 +897,8 @@ EncPlan plan_encoder(const EncoderW& e, int B, int H, int W) {
         if (t5 > ck) ck = t5;
         const int t6 = vt_conv3x3_s2_tiles(hh, ww);
         if (t6 > ck) ck = t6;
+        const int t7 = vt_conv3x3_s2_fp8_tiles(hh, ww);
+        if (t7 > ck) ck = t7;
         if (t1 > ck) ck = t1;
         if (t2 > ck) ck = t2;
         if (ck > p.max_chunks) p.max_chunks = ck;
@@ -1693,6 +1736,14 @@ int vt_op_conv3x3_fp8(vt_context* c, const float* x_nhwc, const float* w_oihw, c
         HIPCK(c, hipMemcpy(mult, mg.data(), mg.size() * 4, hipMemcpyHostToDevice), "vt_op_conv3x3_fp8 copy");
         HIPCK(c, vt_launch_gn_apply(x_nhwc, 1, ss, x8, B, H * W, Cin, 0, s, FP8_RES_SCALE), "vt_op_conv3x3_fp8 quantise");
         ConvW cw; cw.cin = Cin; cw.cout = Cout; cw.k = 3; cw.w8g = w8; cw.mult8g = mult; cw.b = bias;
+        if (c->s2_halo && vt_conv3x3_s2_fp8_supported(Cin, Cout)) {       // the phase-plane kernel's packing instead (same scales)
+            std::vector<float> sc8(Cout);
+            for (int o = 0; o < Cout; ++o) sc8[o] = m8[o] * FP8_ACT_SCALE;
+            std::vector<uint8_t> s2p;
+            pack_conv_s2_fp8(hw.data(), Cout, Cin, sc8.data(), &s2p);
+            HIPCK(c, hipMemcpy(w8, s2p.data(), s2p.size(), hipMemcpyHostToDevice), "vt_op_conv3x3_fp8 copy");
+            cw.wp8s2 = w8;
+        }
         return run_conv(c, cw, (const bf16_t*)x8, B, H, W, 2, 0, H / 2, W / 2, res, o32, nullptr, s, nullptr, 32, nullptr, nullptr, 1, nullptr, true);
     }
     HIPCK(c, vt_launch_gn_apply(x_nhwc, 1, ss, x8, B, H * W, Cin, 0, s, FP8_ACT_SCALE), "vt_op_conv3x3_fp8 quantise");

@@ -56,8 +56,9 @@ constexpr int VT_PROF_GEMM_FP8 = 13;
 constexpr int VT_PROF_S2_HALO = 14;      // stride-2 phase-plane halo conv (conv3x3_s2_halo.hip)
 constexpr int VT_PROF_ATTN_QK8 = 15;     // fp8 Q.K^T / P.V (attn_fp8.hip)
 constexpr int VT_PROF_ATTN_PV8 = 16;
-constexpr int VT_PROF_GN_APPLY = 17;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
-constexpr int VT_NUM_PROF_SLOTS = 18;
+constexpr int VT_PROF_S2_HALO_FP8 = 17;  // stride-2 phase-plane conv on e4m3 operands (conv3x3_s2_halo_fp8.hip)
+constexpr int VT_PROF_GN_APPLY = 18;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 19;
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
@@ -190,6 +191,24 @@ bool vt_conv3x3_s2_supported(int Cin, int Cout);
 int vt_conv3x3_s2_tiles(int Ho, int Wo);                  // GroupNorm partials per image its epilogue writes
 hipError_t vt_launch_conv3x3_s2(const Conv3x3S2Args& a, hipStream_t s);
 hipError_t vt_launch_repack_ohwi_to_s2(const bf16_t* w_ohwi, bf16_t* wp, int Cin, int Cout, hipStream_t s);
+
+// the same on fp8 (e4m3) operands (conv3x3_s2_halo_fp8.hip): out = acc * mult[cout] + bias (+ res)
+struct Conv3x3S2Fp8Args {
+    const unsigned char* X;   // NHWC e4m3 [batch][H][W][Cin] (input scale folded into mult)
+    const unsigned char* Wp;  // packed [Cin/64][9 steps (vt_s2_step_of_tap)][Cout rows (vt_halo_fp8_row_of_cout)][64] e4m3
+    const float* mult;        // [Cout]
+    const float* bias;        // [Cout] or null
+    const float* res;         // optional fp32 residual [batch][Ho][Wo][Cout]
+    float* out_f32; bf16_t* out_bf16; f16_t* out_f16;
+    const void* zeros;
+    float* gn_partial; int gn_cpg;
+    int batch, H, W, Cin, Cout;
+    int Ho, Wo, tiles_x, ctiles, per_img, ptiles;          // filled by the launcher
+    unsigned long long m_per_img, m_ctiles, m_tiles_x;
+};
+bool vt_conv3x3_s2_fp8_supported(int Cin, int Cout);
+int vt_conv3x3_s2_fp8_tiles(int Ho, int Wo);
+hipError_t vt_launch_conv3x3_s2_fp8(const Conv3x3S2Fp8Args& a, hipStream_t s);
 
 // 3x3 stride-1 pad-1 conv on fp8 (OCP e4m3) operands (conv3x3_halo_fp8.hip): out = acc * mult[cout] + bias[cout] (+ residual)
 struct Conv3x3Fp8Args {
