@@ -27,6 +27,14 @@ __device__ unsigned long long* g_halo_stamps = nullptr;
 extern "C" int vt_debug_halo_stamps(unsigned long long* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_halo_stamps), &buf, sizeof(buf));
 }
+// ... or only the nth launch (counted from this call) whose (H, Cin) match: the launcher switches the device pointer on the stream
+static unsigned long long* s_stamp_ptrs[2] = {nullptr, nullptr};      // [0] = off, [1] = the buffer
+static int s_stamp_H = 0, s_stamp_Cin = 0, s_stamp_nth = -1, s_stamp_seen = 0;
+static bool s_stamp_on = false;
+extern "C" int vt_debug_halo_stamps_nth(unsigned long long* buf, int H, int Cin, int nth) {
+    s_stamp_ptrs[1] = buf; s_stamp_H = H; s_stamp_Cin = Cin; s_stamp_nth = buf ? nth : -1; s_stamp_seen = 0; s_stamp_on = false;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_halo_stamps), &s_stamp_ptrs[0], sizeof(void*));
+}
 #ifndef STAMP_TID
 #define STAMP_TID 0
 #endif
@@ -703,6 +711,15 @@ hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
         return (nblk * d < (1LL << 40) && nblk < (1LL << 23)) ? ((1ULL << 40) / (unsigned long long)d + 1ULL) : 0ULL;
     };
     k.m_per_img = magic(k.per_img); k.m_ctiles = magic(k.ctiles); k.m_tiles_x = magic(k.tiles_x);
+#ifdef HALO_STAMP
+    if (s_stamp_nth >= 0) {
+        const bool on = a.H == s_stamp_H && a.Cin == s_stamp_Cin && s_stamp_seen++ == s_stamp_nth;
+        if (on != s_stamp_on) {
+            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_halo_stamps), &s_stamp_ptrs[on ? 1 : 0], sizeof(void*), 0, hipMemcpyHostToDevice, s);
+            s_stamp_on = on;
+        }
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NWV), smem, s, k);
     return hipGetLastError();
 }
