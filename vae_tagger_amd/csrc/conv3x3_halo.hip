@@ -212,6 +212,9 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     const int wstep = a.Cout * 32;               // elements between consecutive K-steps
 
     auto issue_x_dma = [&](int chunk) {          // XT == 0
+#ifdef EXP_NO_DMA                // timing experiment only (wrong results): the first two halos and the first NW weight tiles serve every K-step
+        if (chunk >= 2) return;
+#endif
         char* dst = xbase + (chunk & 1) * XBUF;
         int hy = opaque(hy0), hx = hx0, hr = hr0;
 #pragma nounroll
@@ -229,9 +232,16 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     // the 128-VGPR one, which walks them ky-major (fewer live fragment addresses) and permutes its weight fetches instead.
     constexpr bool KYMAJOR = XT == 0 && TPW == 4;
     auto issue_w = [&](int t, int tap_of_t /* t % 9, a compile-time constant at every call site */) {
+#ifdef EXP_NO_DMA
+        if (t >= NW) return;
+#endif
         char* dst = wbase + (t % NW) * WBUF;
         const int src_t = KYMAJOR ? t - tap_of_t + vt_halo_step_of_tap(tap_of_t) : t;
+#ifdef W_WINDOW_EXPERIMENT       // timing experiment only (wrong results): every K-step's weights from a window of W_WINDOW_EXPERIMENT tiles
+        const bf16_t* wt = a.Wp + (long long)(src_t % W_WINDOW_EXPERIMENT) * wstep + opaque(wsrc0);
+#else
         const bf16_t* wt = a.Wp + (long long)src_t * wstep + opaque(wsrc0);
+#endif
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
             if (WPCS % NLD == 0 || j * NLD + wave < WPCS)
@@ -443,8 +453,10 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 const char* xs_n = (dx == 2) ? xbase + ((chunk + 1) & 1) * XBUF : xs;
                 const char* ws_n = wbase + ((t + 1) % NW) * WBUF + opaque(wfoff);
                 auto refill = [&](int r) {                                 // DYR: halo row r of the next dx group
+#ifndef EXP_NO_FRAG_READS        // timing experiment only (wrong results): the step-0 fragments serve every K-step
                     const int rel = r * HWID + dx_n;
                     xr[r] = *(const bf16x8*)(xs_n + xaddr(rel & 7) + rel * HB);
+#endif
                 };
                 // An LDS-DMA piece costs its wave ~100 issue cycles.  Issued right after the barrier by all 8 waves
                 // at once, that kept the matrix pipe idle (~190 cycles per K-step, in-kernel stamps); instead each
@@ -468,11 +480,13 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                     }
                 }
                 __builtin_amdgcn_s_setprio(0);
+#ifndef EXP_NO_FRAG_READS
                 if (has_next) {
                     // W fragments are live until the last MFMA: refill them now; the reads fly during the barrier wait
 #pragma unroll
                     for (int i = 0; i < TC; ++i) wfc[i] = *(const bf16x8*)(ws_n + i * 16 * HB);
                 }
+#endif
                 continue;
             }
             const char* ws = wbase + (t % NW) * WBUF + opaque(wfoff);     // stage bases beyond 64 KB cannot be ds_read immediates

@@ -135,6 +135,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
     const int wstep = a.Cout * HB;                                     // bytes between consecutive K-steps
 
     auto issue_x_dma = [&](int chunk) {
+#ifdef EXP_NO_DMA                    // timing experiment only (wrong results): the first two halos and the first NW weight tiles serve every K-step
+        if (chunk >= 2) return;
+#endif
         char* dst = xbase + (chunk & 1) * XBUF;
         int hy = opaque(hy0), hx = hx0, hr = hr0;
 #pragma nounroll
@@ -149,8 +152,15 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
         }
     };
     auto issue_w = [&](int t) {
+#ifdef EXP_NO_DMA
+        if (t >= NW) return;
+#endif
         char* dst = wbase + (t % NW) * WBUF;
+#ifdef W_WINDOW_EXPERIMENT       // timing experiment only (wrong results): every K-step's weights from a window of W_WINDOW_EXPERIMENT tiles
+        const unsigned char* wt = a.Wp + (long long)(t % W_WINDOW_EXPERIMENT) * wstep + opaque(wsrc0);
+#else
         const unsigned char* wt = a.Wp + (long long)t * wstep + opaque(wsrc0);
+#endif
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
             __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(wt + j * NWV * 16 * HB), VT_LDS_PTR(dst + (j * NWV + wave) * 1024), 16, 0, 0);
@@ -220,7 +230,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
             const int dx_n = (dx + 1) % 3;
             const char* xs_n = (dx == 2) ? xbase + ((chunk + 1) & 1) * XBUF : xs;
             const char* ws_n = wbase + ((t + 1) % NW) * WBUF;
+#ifndef EXP_NO_FRAG_READS            // timing experiment only (wrong results): the step-0 fragments serve every K-step
             auto refill = [&](int r) { xr[r] = read_frag(xs_n, opaque(xrow0) + r * HWID + dx_n, g); };
+#else
+            auto refill = [&](int) {};
+#endif
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
@@ -238,10 +252,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
                 }
             }
             __builtin_amdgcn_s_setprio(0);
+#ifndef EXP_NO_FRAG_READS
             if (has_next) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) wfc[h] = read_frag(ws_n, opaque(wrow0) + 32 * h, g);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);           // a K-step's MFMAs stay inside it (sunk past later barriers they cost spills)
         }
     };
