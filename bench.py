@@ -144,8 +144,59 @@ def pmc_traffic(kernel, batch, height, width, fp8=False):
     return None, None
 
 
+class SocketPower:
+    """hwmon power1_input / freq1_input of the amdgpu cards, polled from a thread while a region runs (the socket sits at its power
+    cap under this workload, and that -- not issue slots -- sets the MFMA kernels' rate).  The hwmon tree shows every card of the host; the one
+    reported is the card whose power rose most against the idle sample taken before this process touched the GPU.  Absent files: None."""
+    def __init__(self):
+        import glob
+        self.dirs = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        self.idle = [self._read(d, "power1_input") for d in self.dirs]
+        self.rows = []
+
+    @staticmethod
+    def _read(d, f):
+        try:
+            with open(os.path.join(d, f)) as fh:
+                return int(fh.read().strip())
+        except Exception:
+            return None
+
+    def __enter__(self):
+        import threading
+        self.rows, self._stop = [], False
+        def run():
+            while not self._stop:
+                self.rows.append([(self._read(d, "power1_input"), self._read(d, "freq1_input")) for d in self.dirs])
+                time.sleep(0.05)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        self._th.join()
+
+    def summary(self):
+        rows = self.rows[len(self.rows) // 3:]                 # the reading is a moving average: drop the part that still holds the previous phase
+        if not self.dirs or len(rows) < 3:
+            return None
+        med = lambda v: (sorted(v)[len(v) // 2] if v else None)
+        pw = [med([r[i][0] for r in rows if r[i][0] is not None]) for i in range(len(self.dirs))]
+        cand = [i for i in range(len(self.dirs)) if pw[i] is not None]
+        if not cand:
+            return None
+        i = max(cand, key=lambda i: pw[i] - (self.idle[i] or 0))
+        cap = self._read(self.dirs[i], "power1_cap")
+        fq = med([r[i][1] for r in rows if r[i][1] is not None])
+        return {"socket_w_median": round(pw[i] / 1e6, 1), "cap_w": None if cap is None else round(cap / 1e6, 1),
+                "smu_sclk_mhz_median": None if fq is None else round(fq / 1e6), "samples": len(rows),
+                "source": "hwmon power1_input / freq1_input, 50-ms polling during the K untraced steps (rank 0's view; the card whose power rose most)"}
+
+
 def main():
     a = parse()
+    power = SocketPower()
     if a.lib:
         from vae_tagger_amd import _lib
         _lib.LIB_PATH = os.path.abspath(a.lib)
@@ -352,7 +403,9 @@ def main():
     elapsed, out, prof = timed(steps)
     assert torch.isfinite(out).all()
     # the same K steps without the per-launch event records (the production path): reported beside the contract number
-    elapsed_plain, out, _ = timed(steps, profile=False)
+    with power:
+        elapsed_plain, out, _ = timed(steps, profile=False)
+    power_main = power.summary() if rank == 0 else None
     status = prof_ctx.status()
     assert status == 0, (f"vt_status = {status}: " + ("non-finite activations inside the encoder" if status & 1 else
                                                        "activations clamped to the e4m3 range (fp8 mode unsuitable for these weights)"))
@@ -382,7 +435,7 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_step_without_events": round(elapsed_plain / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
-            "config": cfg, "roofline": roof, "hbm_pass": hbm,
+            "config": cfg, "roofline": roof, "hbm_pass": hbm, "power": power_main,
         }
 
     # ---- the other single-GPU configs of BASELINE.json on the same pipeline, attached to the ONE line as "also" (default run only):
@@ -397,7 +450,9 @@ def main():
         try:
             for _ in range(W2):
                 plain_step()
-            e8, out8, prof8 = timed([plain_step] * K2)
+            with power:
+                e8, out8, prof8 = timed([plain_step] * K2)
+            power8 = power.summary()
             also_f8_logits = pipe.logits(x[:1])
             same8 = bool(torch.equal(also_f8_logits[0], out8[0]))
             st8 = prof_ctx.status()
@@ -411,7 +466,8 @@ def main():
             "value": round(ips8, 3), "unit": "images/sec", "steps": K2, "warmup": W2, "ms_per_step": round(e8 / K2 * 1e3, 3), "dtype": "fp8",
             "vt_status": st8, "identical_to_the_batched_result": same8,
             "roofline": {k: roof8[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms", "traffic", "traffic_source", "per_config")},
-            "hbm_pass": {k: hbm8[k] for k in ("achieved", "frac", "share_of_step")}}
+            "hbm_pass": {k: hbm8[k] for k in ("achieved", "frac", "share_of_step")},
+            "power": None if power8 is None else {k: power8[k] for k in ("socket_w_median", "cap_w", "smu_sclk_mhz_median", "samples")}}
         also["configs4_fp8_per_gpu"].update(end_to_end(ips8, fimg, fl8_8 / (B * K2)))
         plan3 = make_bucket_plan(W2 + K2)
         for p3 in plan3[:W2]:

@@ -321,12 +321,13 @@ def test_fp8_stride2_conv_matches_torch_on_the_same_quantised_operands(ops, s2_h
 
 def test_fp8_stride2_conv_one_hot_taps(ops):
     """The fp8 phase-plane kernel with one-hot weights, one tap at a time, on small-integer inputs (exact in e4m3): every tap must read
-    in(2y + ky, 2x + kx) exactly."""
+    in(2y + ky, 2x + kx) exactly.  (The weight is 0.875, not 1: the kernel returns acc * (amax / 448) and 1 / 448 is not a float -- with 1.0 the
+    outputs +-3, +-6, +-7 come back one ulp off, as the first GPU run of this test showed.)"""
     Cin = Cout = 128
     x = (torch.arange(2 * Cin * 19 * 70, dtype=torch.float32).reshape(2, Cin, 19, 70) % 17) - 8.0
     for tap in range(9):
         w = torch.zeros(Cout, Cin, 3, 3)
-        w[torch.arange(Cout), torch.arange(Cin), tap // 3, tap % 3] = 1.0
+        w[torch.arange(Cout), torch.arange(Cin), tap // 3, tap % 3] = 0.875      # per-cout scale 0.875 / 448 = 2^-9: the epilogue's acc * scale is exact
         ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, stride=2)
         got = ops.conv3x3_fp8(x, w, stride=2)
         assert got.shape == ref.shape and torch.equal(got, ref), f"tap {tap}"

@@ -128,14 +128,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
 
 // one workgroup of FIN_T threads per (image, group): merges [nparts] (n, mean, M2) triples -- written by gn_stats_kernel or by a
 // conv epilogue -- with a fixed thread<-part assignment, in fp64, then xor-shuffle trees and a fixed-order merge of the waves
-// => deterministic.  (Four waves instead of one: the 4096-partial tensors of the 1024^2 stage took 66 us per call on 64 lanes.)
-constexpr int FIN_T = 256;
+// => deterministic.  (Sixteen waves: the 4096-partial tensors of the 1024^2 stage took 66-71 us per call on four waves -- two dependent
+// sweeps of 16 strided loads per thread, all latency -- and 4 launches of a step sit between convs with nothing to hide them under.)
+constexpr int FIN_T = 1024;
 __global__ __launch_bounds__(FIN_T) void gn_finalize_kernel(const float* __restrict__ partial, int nparts, int C,
                                                             int groups, float eps, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
                                                             float* __restrict__ scale_shift, int* __restrict__ status) {
     __shared__ double red[FIN_T / 64][2];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6;
+    const int nt = blockDim.x;                                // 256, or FIN_T for the large partial tensors (the launcher's choice)
     const int cpg = C / groups;
     const float* pb = partial + ((long long)b * nparts * groups + g) * 3;
     auto block_sum2 = [&](double& a0, double& a1) {           // sums over the workgroup, identical in every thread
@@ -145,11 +147,10 @@ __global__ __launch_bounds__(FIN_T) void gn_finalize_kernel(const float* __restr
         if ((tid & 63) == 0) { red[wave][0] = a0; red[wave][1] = a1; }
         __syncthreads();
         a0 = 0.0; a1 = 0.0;
-#pragma unroll
-        for (int w = 0; w < FIN_T / 64; ++w) { a0 += red[w][0]; a1 += red[w][1]; }
+        for (int w = 0; w < (nt >> 6); ++w) { a0 += red[w][0]; a1 += red[w][1]; }
     };
     double n = 0.0, s = 0.0;
-    for (int c = tid; c < nparts; c += FIN_T) {
+    for (int c = tid; c < nparts; c += nt) {
         const float* t = pb + (long long)c * groups * 3;
         n += (double)t[0];
         s += (double)t[0] * (double)t[1];
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(FIN_T) void gn_finalize_kernel(const float* __restr
     block_sum2(n, s);
     const double mean = s / n;
     double m2 = 0.0, unused = 0.0;
-    for (int c = tid; c < nparts; c += FIN_T) {
+    for (int c = tid; c < nparts; c += nt) {
         const float* t = pb + (long long)c * groups * 3;
         const double d = (double)t[1] - mean;
         m2 += (double)t[2] + (double)t[0] * d * d;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(FIN_T) void gn_finalize_kernel(const float* __restr
     if (status && tid == 0 && !(fabs(mean) <= 1.0e300 && fabs(var) <= 1.0e300)) atomicOr(status, 1);
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float fmean = (float)mean;
-    for (int c = tid; c < cpg; c += FIN_T) {
+    for (int c = tid; c < cpg; c += nt) {
         const int ch = g * cpg + c;
         const float sc = rstd * gamma[ch];
         float* o = scale_shift + ((long long)b * C + ch) * 2;
@@ -292,7 +293,7 @@ hipError_t vt_launch_gn_stats(const void* x, int x_dtype, int B, int HW, int C, 
 hipError_t vt_launch_gn_finalize(const float* partial, int nparts, int B, int C, int groups, float eps,
                                  const float* gamma, const float* beta, float* scale_shift, hipStream_t s, int* status) {
     if (C <= 0 || groups <= 0 || C % groups || nparts <= 0 || B <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(FIN_T), 0, s, partial, nparts, C, groups, eps, gamma,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(nparts >= 2048 ? FIN_T : 256), 0, s, partial, nparts, C, groups, eps, gamma,
                        beta, scale_shift, status);
     return hipGetLastError();
 }
