@@ -141,11 +141,19 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         own kernel that loads them straight into registers (only v^T passes through LDS); 0 = row-major P + the generic GEMM.
  * flag 11: 1 = BASELINE.json configs[4]: all 23 3x3 convolutions of the resnet / downsample stack run on fp8 (OCP e4m3) operands on
  *         the fp8 MFMA (2x the bf16 rate): the 20 stride-1 convs on v_mfma_scale_f32_32x32x64_f8f6f4 (conv3x3_halo_fp8.hip), the
- *         three stride-2 convs on v_mfma_scale_f32_16x16x128_f8f6f4 (conv_gemm.hip, F8).  Weights e4m3 with per-output-channel
- *         scales; activations e4m3(8 x) written by the GroupNorm-apply pass, the block output feeding a stride-2 conv e4m3(x);
- *         fp32 accumulate; conv_in, conv_out, the 1x1 shortcuts and the attention stay bf16 / fp32.  OPT-IN, for tagging only:
- *         latents move by ~1e-1 (max; rms 2e-2), logits stay within 1e-2 of the CPU reference (measured 4.4e-3;
- *         tests/diagnostics/fp8_study.py).  0 (default) = bf16.
+ *         three stride-2 convs on the same instruction over the input's phase planes (conv3x3_s2_halo_fp8.hip; flag 13).  Weights e4m3
+ *         with per-output-channel scales; activations e4m3(8 x) written by the GroupNorm-apply pass, the block output feeding a
+ *         stride-2 conv e4m3(x); fp32 accumulate.  The mid-block attention follows (flags 14, 15); conv_in, conv_out, the 1x1
+ *         shortcuts and to_out stay bf16 / fp32.  OPT-IN, for tagging only: latents move by ~1e-1 (max; rms 2e-2), logits stay
+ *         within 1e-2 of the CPU reference (measured 4-5e-3; tests/diagnostics/fp8_study.py).  0 (default) = bf16.
+ * flag 13: 1 (default) = the three stride-2 convs (Downsample2D) run on the phase-plane halo kernels (conv3x3_s2_halo.hip, and
+ *         conv3x3_s2_halo_fp8.hip in fp8 mode); 0 = on the generic implicit GEMM (bf16, or its e4m3 variant).
+ * flag 14: 1 (default) = in fp8 mode Q.K^T and P.V multiply e4m3 operands on v_mfma_scale_f32_16x16x128_f8f6f4 (attn_fp8.hip: q8 | k8 =
+ *         e4m3(8 q | 8 k), v8^T, numerators e4m3(32 exp(s - sampled row maximum)) with a device-side overflow flag and a gated exact
+ *         redo; flag 7 = 1: always the exact maximum); 0 = the bf16 attention kernels in fp8 mode too.
+ * flag 15: 1 (default) = with flag 14, the q | k and v projections multiply e4m3 operands too (tokens e4m3(8 x) from the GroupNorm pass,
+ *         [Wq; Wk] and Wv as e4m3(W / s), one scale per matrix) and write q8 | k8 and v8^T directly (proj_fp8_kernel); 0 = bf16
+ *         projections followed by conversion passes.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

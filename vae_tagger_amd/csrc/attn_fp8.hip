@@ -242,6 +242,135 @@ __global__ __launch_bounds__(512, 2) void attn_qk_fp8_kernel(const AttnQk8Args a
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Linear projections of the fp8 mode on the same skeleton (rows of one operand resident in registers as a 32-row slab per wave, the other
+// operand's rows streamed through LDS as 128-row tiles under the key -> LDS-row map above, so that a lane's accumulators over a tile are 32
+// CONSECUTIVE "keys"): out8[q][k] = e4m3(clamp(oscale * (alpha * q8[q] . k8[k] + kbias[k] + qbias[q]))), 16-B stores of 16 consecutive k.
+//   q | k projection: q rows = tokens e4m3(8 x^) [S][512], k rows = [Wq; Wk] as e4m3(W / s) [1024][512]  ->  q8 | k8 [S][1024] directly
+//                     (no bf16 q | k, no conversion pass);
+//   v projection:     q rows = Wv as e4m3(W / s) [512][512] (shared by the batch), k rows = tokens  ->  v8^T [512][pitch] directly.
+// K = 512 = four k-steps, so a tile is 64 MFMAs per wave; the epilogue is one fma + clamp + convert per value.
+__global__ __launch_bounds__(512, 2) void proj_fp8_kernel(const ProjFp8Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 key tiles
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int qtiles = (a.nq + QB - 1) / QB;
+    const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
+    const int logical = vt_xcd_remap(blockIdx.x, gridDim.x);
+    const int per_img = qtiles * nsplit;
+    const int b = logical / per_img, qs = logical - b * per_img;
+    const int qt = qs / nsplit, ksp = qs - qt * nsplit;
+    const unsigned char* qb = a.q8 + (long long)b * a.q_bs;
+    const unsigned char* kb = a.k8 + (long long)b * a.k_bs;
+    const int row0 = qt * QB + wave * 32;
+
+    i32x8 qf[2][4];
+    float qbias[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = row0 + j * 16 + fr;
+        const unsigned char* src = row < a.nq ? qb + (long long)row * a.ldq + fq * 32 : (const unsigned char*)a.zeros;
+        const int step = row < a.nq ? 128 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[j][ks] = cat8(*(const i32x4*)(src + ks * step), *(const i32x4*)(src + ks * step + (row < a.nq ? 16 : 0)));
+        qbias[j] = (a.qbias && row < a.nq) ? a.qbias[row] * a.oscale : 0.f;
+    }
+    const float alpha = a.alpha * a.oscale;
+
+    const int sr_ = 2 * wave + (lane >> 5);
+    const int skey = 32 * (sr_ >> 2) + (sr_ & 3);
+    const int schunk = ((lane & 31) ^ sr_) << 4;
+    auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+        const int key_l = kt * KT + opaque8(skey);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int key = key_l + 16 * (jj >> 2) + 4 * (jj & 3);
+            const void* src = key < a.nk ? (const void*)(kb + (long long)key * a.ldk + schunk) : a.zeros;
+            __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(smem + buf * KBUF + (jj * 8 + wave) * 1024), 16, 0, 0);
+        }
+    };
+    int kbase[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) kbase[p][h] = fr * KROWB + ((((8 * p + 2 * fq + h) ^ fr) & 15) << 4);
+
+    f32x4 acc[4][2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    unsigned clampw = 0;
+    const int nkt_all = (a.nk + KT - 1) / KT;
+    const int kt0 = (int)((long long)ksp * nkt_all / nsplit), kt1 = (int)((long long)(ksp + 1) * nkt_all / nsplit);
+    unsigned char* const ob = a.out8 + (long long)b * a.o_bs;
+
+    // half h of tile kt (in acc) -> 16 bytes per query tile: keys kt * 128 + 32 fq + 16 h .. + 15 of rows row0 + 16 j + fr
+    auto epilogue_half = [&](int kt, int h) __attribute__((always_inline)) {
+        const int key0 = kt * KT + 32 * fq + 16 * h;
+        i32x4 outw[2];
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            const f32x4 kbv = (a.kbias && key0 + 4 * mm + 3 < a.nk) ? *(const f32x4*)(a.kbias + key0 + 4 * mm) * a.oscale : zero4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaf(acc[mm][j][r], alpha, kbv[r] + qbias[j]);
+                    v = __builtin_amdgcn_fmed3f(v, -448.f, 448.f);
+                    e[r] = (key0 + 4 * mm + r < a.nk) ? v : 0.f;
+                }
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w, true);
+                clampw |= (((unsigned)w & 0x7f7f7f7fu) + 0x02020202u) & 0x80808080u;      // a byte of +-448: the value met the clamp
+                outw[j][mm] = w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = row0 + j * 16 + fr;
+            if (row < a.nq && key0 < a.kext) *(i32x4*)(ob + (long long)row * a.ldo + key0) = outw[j];
+        }
+    };
+
+    int it = 0;
+    if (kt0 < kt1) stage(kt0, 0);
+    for (int kt = kt0; kt < kt1; ++kt, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < kt1) stage(kt + 1, (it + 1) & 1);
+        const char* ks_base = smem + (it & 1) * KBUF;
+        constexpr int AHEAD = 3, RING = 4;
+        auto half = [&](int h /* compile-time */) __attribute__((always_inline)) {
+            i32x8 kf[RING];
+            auto frag = [&](int idx) __attribute__((always_inline)) -> i32x8 {
+                const int ks = idx >> 2, m = 4 * h + (idx & 3);
+                const char* p = ks_base + (ks >> 1) * 256 + m * 16 * KROWB;
+                return cat8(*(const i32x4*)(p + kbase[ks & 1][0]), *(const i32x4*)(p + kbase[ks & 1][1]));
+            };
+#pragma unroll
+            for (int p = 0; p < AHEAD; ++p) kf[p] = frag(p);
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) {
+                if (idx + AHEAD < 16) kf[(idx + AHEAD) % RING] = frag(idx + AHEAD);
+                const int ks = idx >> 2, mm = idx & 3;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mm][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kf[idx % RING], qf[j][ks], ks == 0 ? zero4 : acc[mm][j], 0, 0, 0, 127, 0, 127);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        half(0);
+        epilogue_half(kt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        half(1);
+        epilogue_half(kt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (a.status && __any(clampw != 0u) && lane == 0) atomicOr(a.status, 2);          // VT_STATUS_FP8_SATURATED
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // P.V: o[q][c] = (1 / (8 sum_q)) sum_k P8[q][k] v8^T[c][k]
 constexpr int ROWB = KT;       // bytes per LDS row of the v^T tile (one channel, 128 keys)
 
@@ -400,6 +529,25 @@ hipError_t vt_launch_attn_qk_fp8(const AttnQk8Args& a, hipStream_t s) {
     if (ea != hipSuccess) return ea;
     if (a.mode == 1) hipLaunchKernelGGL(attn_qk_fp8_kernel<1>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
     else hipLaunchKernelGGL(attn_qk_fp8_kernel<3>, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
+    return hipGetLastError();
+}
+
+hipError_t vt_launch_proj_fp8(const ProjFp8Args& a, hipStream_t s) {
+    if (!a.q8 || !a.k8 || !a.out8 || !a.zeros || a.batch <= 0 || a.nq <= 0 || a.nk <= 0 || a.C != D) return hipErrorInvalidValue;
+    if ((a.ldq % 16) || (a.q_bs % 16) || (a.ldk % 16) || (a.k_bs % 16) || (a.ldo % 16) || (a.o_bs % 16) || (a.kext % 16)) return hipErrorInvalidValue;
+    if (a.kext > a.ldo || a.kext < a.nk - 15 || ((uintptr_t)a.out8 % 16)) return hipErrorInvalidValue;      // whole 16-byte chunks inside a row's pitch
+    if (a.kbias && (a.nk % 4)) return hipErrorInvalidValue;
+    if ((long long)a.nq * a.ldq >= (1LL << 31) || (long long)a.nk * a.ldk >= (1LL << 31)) return hipErrorInvalidValue;
+    const int nkt = (a.nk + KT - 1) / KT;
+    if (a.nsplit < 0 || a.nsplit > nkt) return hipErrorInvalidValue;
+    const long long nblk = (long long)((a.nq + QB - 1) / QB) * a.batch * (a.nsplit > 1 ? a.nsplit : 1);
+    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    static std::atomic<unsigned long long> attr_done{0};
+    hipError_t ea = vt_once_per_device(attr_done, [&] {
+        return hipFuncSetAttribute((const void*)proj_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF);
+    });
+    if (ea != hipSuccess) return ea;
+    hipLaunchKernelGGL(proj_fp8_kernel, dim3((unsigned)nblk), dim3(512), 2 * KBUF, s, a);
     return hipGetLastError();
 }
 

@@ -36,7 +36,9 @@ struct ResnetW {
     const bf16_t* sc_wp = nullptr; const float* b_c2sc = nullptr;
     const bf16_t* sc_wp8 = nullptr;      // the same for the fp8 conv2: rows in its cout order, values divided by conv2's mult[cout]
 };
-struct AttnW { NormW gn; const bf16_t *wqk = nullptr, *wv = nullptr, *wo = nullptr; const float *bqk = nullptr, *bv = nullptr, *bo = nullptr; int c = 0; };
+struct AttnW { NormW gn; const bf16_t *wqk = nullptr, *wv = nullptr, *wo = nullptr; const float *bqk = nullptr, *bv = nullptr, *bo = nullptr; int c = 0;
+               // fp8 mode's projections (proj_fp8_kernel): [Wq; Wk] and Wv as e4m3(W / s), one scale per matrix
+               const unsigned char *wqk8 = nullptr, *wv8 = nullptr; float sqk = 1.f, sv = 1.f; };
 struct StageW { std::vector<ResnetW> res; bool has_down = false; ConvW down; };
 
 struct EncoderW {
@@ -147,6 +149,7 @@ struct vt_context {
     int fp8 = 0;                    // vt_set_flag(ctx, 11, v): stride-1 3x3 resnet convs on fp8 (e4m3) operands (BASELINE configs[4])
     int halo_occ2 = 3;              // vt_set_flag(ctx, 3, v): two-workgroups-per-CU tile mode of the halo conv
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
+    int proj_fp8 = 1;               // vt_set_flag(ctx, 15, v): with the fp8 attention, the q | k and v projections on e4m3 operands too, writing q8 | k8 and v8^T directly
     int attn_fp8 = 1;               // vt_set_flag(ctx, 14, v): in fp8 mode (flag 11) Q.K^T and P.V run on e4m3 operands too (attn_fp8.hip)
     int s2_halo = 1;                // vt_set_flag(ctx, 13, v): stride-2 convs on the phase-plane halo kernel instead of the generic GEMM
     // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
@@ -602,6 +605,7 @@ int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, 
 struct AttnScratch {
     bf16_t* qk; bf16_t* vt; f16_t* scores; bf16_t* probs; bf16_t* o;
     unsigned char* qk8; unsigned char* vt8;     // fp8 attention operands: e4m3(8 q | 8 k) [B][S][2C], e4m3(8 v^T) [B][C][attn_pitch8(S)]
+    unsigned char* x8; float* ident;            // op-level entry only: e4m3(8 x) tokens made from the caller's bf16 ones, and the identity (scale, shift) that pass takes
     float* qn; float* kn; float* sd; float* shift; float* rinv; float* part; int* flags;
     int group;
 };
@@ -644,7 +648,7 @@ size_t attn_scratch_bytes(int B, int S, int C) {
     return align_up((size_t)B * S * 2 * C * 2) + align_up((size_t)B * C * ld * 2) + align_up(G * S * ld * 2) +
            align_up(G * attn_p_elems(S) * 2) + align_up((size_t)B * S * C * 2) + 5 * align_up((size_t)B * S * 4) +
            align_up(G * attn_slots_bound(S) * S * 4) + align_up((size_t)B * 4) + align_up((size_t)B * S * 2 * C) +
-           align_up((size_t)B * C * attn_pitch8(S));
+           align_up((size_t)B * C * attn_pitch8(S)) + align_up((size_t)B * S * C) + align_up((size_t)B * C * 2 * 4);
 }
 AttnScratch carve_attn(char* p, int B, int S, int C) {
     const size_t ld = attn_pitch(S), G = (size_t)attn_group(B, S);
@@ -663,19 +667,79 @@ AttnScratch carve_attn(char* p, int B, int S, int C) {
     a.part = (float*)p; p += align_up(G * attn_slots_bound(S) * S * 4);
     a.flags = (int*)p; p += align_up((size_t)B * 4);
     a.qk8 = (unsigned char*)p; p += align_up((size_t)B * S * 2 * C);
-    a.vt8 = (unsigned char*)p;
+    a.vt8 = (unsigned char*)p; p += align_up((size_t)B * C * attn_pitch8(S));
+    a.x8 = (unsigned char*)p; p += align_up((size_t)B * S * C);
+    a.ident = (float*)p;
     return a;
 }
 
 // diffusers Attention for the VAE mid block: 1 head, dim_head = C, scale 1/sqrt(C).
 // x16: group-normed tokens [B][S][C] bf16.  out = to_out(softmax(q k^T / sqrt(C)) v) + residual.
+// does the attention of this context take the e4m3 kernels (attn_fp8.hip) at this size -- and its projections too?
+bool attn_is_fp8(const vt_context* c, int S, int C) {
+    return c->fp8 && c->attn_fp8 && c->attn_mode != 2 && c->attn_qk_kernel && vt_attn_qk_supported(S, C) && vt_attn_fp8_supported(S, C) &&
+           (size_t)vt_attn_p8_bytes(S) <= attn_p_elems(S) * 2;
+}
+bool attn_proj_is_fp8(const vt_context* c, const AttnW& w, int S, int C) { return attn_is_fp8(c, S, C) && c->proj_fp8 && w.wqk8 && w.wv8; }
+
+// `x_e4m3`: x16 holds the tokens as e4m3(8 x) bytes ([B][S][C], one byte each) -- what the encoder's GroupNorm pass writes when
+// attn_proj_is_fp8(); with bf16 tokens on that path (the op-level entry) they are converted here first.
 int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* res, void* out, int B, int S,
-                  const AttnScratch& sc, hipStream_t s, GnState* gn = nullptr, int groups = 32, int rdt = 1) {
+                  const AttnScratch& sc, hipStream_t s, GnState* gn = nullptr, int groups = 32, int rdt = 1, bool x_e4m3 = false) {
     const int C = w.c;
     const int ld = (S + 7) / 8 * 8;                 // K extent of P.V (columns [S, ld) of P are zero)
     const int lp = (int)attn_pitch(S);              // row pitch of scores / P / v^T
+    const bool f8 = attn_is_fp8(c, S, C);
+    const bool p8 = attn_proj_is_fp8(c, w, S, C);
+    const int ld8 = (int)attn_pitch8(S), kext8 = (S + 15) / 16 * 16;
+    if (x_e4m3 && !p8) return c->fail(VT_ERR_STATE, "internal: e4m3 tokens for a bf16 projection");
     ConvGemmArgs a{};
     a.zeros = c->zeros; a.ksize = 1; a.stride = 1; a.pad = 0; a.Hin = a.Hout = 1; a.alpha = 1.f;
+    if (p8) {
+        // fp8 mode: q8 | k8 = e4m3(8 (x Wqk^T + bqk)) and v8^T = e4m3(8 (Wv x^T + bv)) straight from e4m3 operands (proj_fp8_kernel): no bf16
+        // q | k / v^T tensors, no conversion passes.  One scale per weight matrix (e4m3's normal range spans 2^15).
+        const unsigned char* x8 = (const unsigned char*)x16;
+        if (!x_e4m3) {
+            std::vector<float> id((size_t)B * C * 2);
+            for (size_t i = 0; i < id.size(); i += 2) { id[i] = 1.f; id[i + 1] = 0.f; }
+            HIPCK(c, hipMemcpyAsync(sc.ident, id.data(), id.size() * 4, hipMemcpyHostToDevice, s), "attn tokens -> e4m3");
+            HIPCK(c, hipStreamSynchronize(s), "attn tokens -> e4m3");                       // (`id` leaves scope; op-level entry only)
+            HIPCK(c, vt_launch_gn_apply(x16, 0, sc.ident, sc.x8, B, S, C, 0, s, FP8_ACT_SCALE, c->status), "attn tokens -> e4m3");
+            x8 = sc.x8;
+        }
+        ProjFp8Args pq{};
+        pq.q8 = x8; pq.ldq = C; pq.q_bs = (long long)S * C; pq.nq = S;
+        pq.k8 = w.wqk8; pq.ldk = C; pq.k_bs = 0; pq.nk = 2 * C;
+        pq.out8 = sc.qk8; pq.ldo = 2 * C; pq.o_bs = (long long)S * 2 * C; pq.kext = 2 * C;
+        pq.kbias = w.bqk; pq.alpha = w.sqk / FP8_ACT_SCALE; pq.oscale = FP8_QK_SCALE; pq.status = c->status;
+        pq.C = C; pq.batch = B; pq.zeros = c->zeros;
+        auto split_for = [](long long qblocks, int nkt) { int n = 1; while (n < nkt && qblocks * n < 512) n *= 2; return n < nkt ? n : nkt; };
+        pq.nsplit = split_for((long long)B * ((S + 255) / 256), (2 * C + 127) / 128);
+        ProjFp8Args pv{};
+        pv.q8 = w.wv8; pv.ldq = C; pv.q_bs = 0; pv.nq = C;
+        pv.k8 = x8; pv.ldk = C; pv.k_bs = (long long)S * C; pv.nk = S;
+        pv.out8 = sc.vt8; pv.ldo = ld8; pv.o_bs = (long long)C * ld8; pv.kext = kext8;
+        pv.qbias = w.bv; pv.alpha = w.sv / FP8_ACT_SCALE; pv.oscale = FP8_QK_SCALE; pv.status = c->status;
+        pv.C = C; pv.batch = B; pv.zeros = c->zeros;
+        pv.nsplit = split_for((long long)B * ((C + 255) / 256), (S + 127) / 128);
+        if (c->profiling) {
+            vt_context::ProfRec r0, r1;
+            r0.e0 = c->next_event(); r0.e1 = c->next_event(); r1.e0 = c->next_event(); r1.e1 = c->next_event();
+            if (!r0.e0 || !r0.e1 || !r1.e0 || !r1.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+            r0.flops = 2.0 * B * (double)S * 2 * C * C; r1.flops = 2.0 * B * (double)S * C * C;
+            r0.cfg = r1.cfg = VT_PROF_PROJ_FP8;
+            HIPCK(c, hipEventRecord(r0.e0, s), "hipEventRecord");
+            HIPCK(c, vt_launch_proj_fp8(pq, s), "attn qk proj fp8");
+            HIPCK(c, hipEventRecord(r0.e1, s), "hipEventRecord");
+            HIPCK(c, hipEventRecord(r1.e0, s), "hipEventRecord");
+            HIPCK(c, vt_launch_proj_fp8(pv, s), "attn v proj fp8");
+            HIPCK(c, hipEventRecord(r1.e1, s), "hipEventRecord");
+            c->prof.push_back(r0); c->prof.push_back(r1);
+        } else {
+            HIPCK(c, vt_launch_proj_fp8(pq, s), "attn qk proj fp8");
+            HIPCK(c, vt_launch_proj_fp8(pv, s), "attn v proj fp8");
+        }
+    } else {
     // q | k = x Wqk^T + bqk  -> [B][S][2C]
     a.X = x16; a.W = w.wqk; a.bias = w.bqk; a.bias_mode = 1; a.out_bf16 = sc.qk; a.out_f32 = nullptr;
     a.Win = a.Wout = S; a.Cin = C; a.Cout = 2 * C; a.Wrows = 2 * C; a.ldx = C; a.ldw = C; a.ldo = 2 * C;
@@ -686,22 +750,20 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
     a.Win = a.Wout = C; a.Cin = C; a.Cout = ld; a.Wrows = S; a.ldx = C; a.ldw = C; a.ldo = lp;
     a.x_bs = 0; a.w_bs = (long long)S * C; a.o_bs = (long long)C * lp; a.batch = B;
     HIPCK(c, launch_gemm(c, a, s), "attn v proj");
+    }
     const float scale = 1.0f / sqrtf((float)C);
-    const bool f8 = c->fp8 && c->attn_fp8 && c->attn_mode != 2 && c->attn_qk_kernel && vt_attn_qk_supported(S, C) && vt_attn_fp8_supported(S, C) &&
-                    (size_t)vt_attn_p8_bytes(S) <= attn_p_elems(S) * 2;
-    const int ld8 = (int)attn_pitch8(S), kext8 = (S + 15) / 16 * 16;
     const int mode = c->attn_mode;                  // 0: exponent shift from operand norms, exact row maximum if flagged;
                                                     // 1: always the exact row maximum; 2: scores -> softmax pass -> P
     if (f8) {
         HIPCK(c, hipMemsetAsync(sc.flags, 0, (size_t)((B + sc.group - 1) / sc.group) * 4, s), "attn flags");
-        // (q8 | k8 come out of the row-norms pass; the norms themselves are not used: the fp8 path takes a sampled / the exact row maximum)
-        HIPCK(c, vt_launch_attn_row_norms_fp8(sc.qk, (long long)B * S, C, FP8_QK_SCALE, sc.qk8, sc.qn, sc.kn, sc.sd, c->status, s), "attn q|k -> e4m3");
+        // (bf16 projections: q8 | k8 come out of the row-norms pass; the norms themselves are not used: the fp8 path takes a sampled / the exact row maximum)
+        if (!p8) HIPCK(c, vt_launch_attn_row_norms_fp8(sc.qk, (long long)B * S, C, FP8_QK_SCALE, sc.qk8, sc.qn, sc.kn, sc.sd, c->status, s), "attn q|k -> e4m3");
     } else if (mode == 0) {
         HIPCK(c, hipMemsetAsync(sc.flags, 0, (size_t)((B + sc.group - 1) / sc.group) * 4, s), "attn flags");
         HIPCK(c, vt_launch_attn_row_norms(sc.qk, (long long)B * S, C, sc.qn, sc.kn, sc.sd, s), "attn row norms");
         HIPCK(c, vt_launch_attn_shift(sc.qn, sc.kn, sc.sd, B, S, scale, 120.f, sc.shift, sc.flags, sc.group, s), "attn shift");
     }
-    if (f8) HIPCK(c, vt_launch_attn_vt_to_fp8(sc.vt, (long long)C * lp, lp, sc.vt8, (long long)C * ld8, ld8, S, kext8, C, B, FP8_QK_SCALE, s), "attn v^T fp8");
+    if (f8 && !p8) HIPCK(c, vt_launch_attn_vt_to_fp8(sc.vt, (long long)C * lp, lp, sc.vt8, (long long)C * ld8, ld8, S, kext8, C, B, FP8_QK_SCALE, s), "attn v^T fp8");
     for (int b0 = 0; b0 < B; b0 += sc.group) {
         const int nb = (B - b0 < sc.group) ? B - b0 : sc.group;
         const bf16_t* q = sc.qk + (long long)b0 * S * 2 * C;
@@ -1060,7 +1122,18 @@ int vt_encoder_finalize(vt_context* c) {
         e.attn.bqk = (const float*)c->upload(bqk.data(), bqk.size() * 4);
         e.attn.bv = (const float*)c->upload(bv.data(), bv.size() * 4);
         e.attn.bo = (const float*)c->upload(bo.data(), bo.size() * 4);
-        if (!e.attn.wqk || !e.attn.wv || !e.attn.wo || !e.attn.bqk || !e.attn.bv || !e.attn.bo) return c->fail(VT_ERR_HIP, "upload failed for attention");
+        auto pack8 = [&](const std::vector<uint16_t>& w, float* scale) -> const unsigned char* {
+            float amax = 0.f;
+            for (uint16_t h : w) amax = fmaxf(amax, fabsf(bf2f(h)));
+            const float sc = amax > 0.f ? amax / 448.f : 1.f;
+            *scale = sc;
+            std::vector<uint8_t> o(w.size());
+            for (size_t i = 0; i < w.size(); ++i) o[i] = f2e4m3(bf2f(w[i]) / sc);
+            return (const unsigned char*)c->upload(o.data(), o.size());
+        };
+        e.attn.wqk8 = pack8(wqk, &e.attn.sqk);
+        e.attn.wv8 = pack8(wv, &e.attn.sv);
+        if (!e.attn.wqk || !e.attn.wv || !e.attn.wo || !e.attn.bqk || !e.attn.bv || !e.attn.bo || !e.attn.wqk8 || !e.attn.wv8) return c->fail(VT_ERR_HIP, "upload failed for attention");
     }
     if ((r = get_norm(c, "encoder.conv_norm_out", C, &e.norm_out))) return r;
     if ((r = get_conv(c, "encoder.conv_out", 2 * e.latent, C, 3, &e.conv_out))) return r;
@@ -1209,8 +1282,9 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
     if ((r = resnet(e.mid0, nullptr, false))) return r;
     {
         const int S = h * w, nxt = (cur + 1) % 3;
-        if ((r = run_gn(c, f32[cur], rdt, B, S, e.attn.gn, e.groups, 0, act, gn, s))) return r;
-        if ((r = run_attention(c, e.attn, act, f32[cur], f32[nxt], B, S, as, s, &gn, e.groups, rdt))) return r;
+        const bool tok8 = attn_proj_is_fp8(c, e.attn, S, C);       // the tokens leave the GroupNorm pass as e4m3(8 x): the projections' operand
+        if ((r = run_gn(c, f32[cur], rdt, B, S, e.attn.gn, e.groups, 0, act, gn, s, tok8))) return r;
+        if ((r = run_attention(c, e.attn, act, f32[cur], f32[nxt], B, S, as, s, &gn, e.groups, rdt, tok8))) return r;
         cur = nxt;
     }
     if ((r = resnet(e.mid1, nullptr, false))) return r;
@@ -1433,6 +1507,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 12) { c->attn_pv_kernel = value != 0; return VT_OK; }
     if (flag == 13) { c->s2_halo = value != 0; return VT_OK; }
     if (flag == 14) { c->attn_fp8 = value != 0; return VT_OK; }
+    if (flag == 15) { c->proj_fp8 = value != 0; return VT_OK; }
     if (flag == 7) {
         if (value < 0 || value > 2) return c->fail(VT_ERR_INVALID, "vt_set_flag(7): value %d not in 0..2", value);
         c->attn_mode = value;

@@ -57,8 +57,9 @@ constexpr int VT_PROF_S2_HALO = 14;      // stride-2 phase-plane halo conv (conv
 constexpr int VT_PROF_ATTN_QK8 = 15;     // fp8 Q.K^T / P.V (attn_fp8.hip)
 constexpr int VT_PROF_ATTN_PV8 = 16;
 constexpr int VT_PROF_S2_HALO_FP8 = 17;  // stride-2 phase-plane conv on e4m3 operands (conv3x3_s2_halo_fp8.hip)
-constexpr int VT_PROF_GN_APPLY = 18;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
-constexpr int VT_NUM_PROF_SLOTS = 19;
+constexpr int VT_PROF_PROJ_FP8 = 18;     // fp8 mode's q | k and v projections (attn_fp8.hip, proj_fp8_kernel)
+constexpr int VT_PROF_GN_APPLY = 19;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 20;
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
@@ -116,6 +117,20 @@ struct AttnQk8Args {
     int batch, nsplit;
     const void* zeros;
 };
+// Linear projections of the fp8 mode (attn_fp8.hip, proj_fp8_kernel): out8[q][k] = e4m3(clamp(oscale * (alpha * q8[q] . k8[k] + kbias[k] + qbias[q])))
+struct ProjFp8Args {
+    const unsigned char* q8; int ldq; long long q_bs; int nq;   // rows held in registers: [nq][ldq] e4m3, C k-bytes each (batch stride may be 0)
+    const unsigned char* k8; int ldk; long long k_bs; int nk;   // rows streamed through LDS: [nk][ldk]
+    unsigned char* out8; int ldo; long long o_bs;               // [nq][ldo] e4m3; columns [nk, kext) are written as zero, kext <= ldo, kext % 16 == 0
+    int kext;
+    const float* kbias;                                         // optional, per k row
+    const float* qbias;                                         // optional, per q row
+    float alpha, oscale;
+    int* status;                                                // optional: bit 1 (VT_STATUS_FP8_SATURATED) when a value met the +-448 clamp
+    int C, batch, nsplit;                                       // nsplit: the k tiles of a query block over this many workgroups (small grids)
+    const void* zeros;
+};
+hipError_t vt_launch_proj_fp8(const ProjFp8Args& a, hipStream_t s);
 struct AttnPv8Args {
     const unsigned char* P8; long long p_bs;
     const unsigned char* vt8; int ldv; long long vt_bs;   // v^T [C][ldv] e4m3 (keys contiguous); keys >= kext are not read (zero page)
