@@ -85,3 +85,42 @@ def test_attention_lds_reads_are_ahead_of_their_mfmas(attention_asm, kernel):
     # and no drain of the vector-memory counter inside the MFMA stream other than the counted / tile-boundary waits written in the source
     assert not any(re.search(r"scratch_(load|store)", l) for l in ins[[i for i, l in enumerate(ins) if l.startswith("v_mfma")][0]:
                                                                       [i for i, l in enumerate(ins) if l.startswith("v_mfma")][-1]]), name
+
+
+# ---- round 3: register budgets.  Every MFMA kernel of the path runs two waves per SIMD, i.e. <= 256 VGPRs, and the hot ones sit AT that limit: one
+# more live value and the allocator spills dozens of registers into the K-loop (38 spills in the first stride-2 kernel, 70-150 in
+# the fp8 attention when an overflow watch was added).  The table is what the committed sources compile to; a spill that creeps in shows up here, on the
+# CPU, instead of as a few per cent on the GPU.
+_BUDGET = {  # file: {kernel substring: max vgpr_spill_count}
+    "conv3x3_halo": {"conv3x3_halo_kernelILi2ELi2ELi0ELi8ELi4E": 0},
+    "conv3x3_halo_fp8": {"conv3x3_halo_fp8_kernel": 0},
+    "conv3x3_s2_halo": {"conv3x3_s2_halo_kernel": 3},            # three, in the last chunk's epilogue hand-over, none in the steady-state loop
+    "conv3x3_s2_halo_fp8": {"conv3x3_s2_halo_fp8_kernel": 0},
+    "attn_fp8": {"attn_qk_fp8_kernelILi1E": 0, "attn_qk_fp8_kernelILi3E": 0, "attn_pv_fp8_kernelILi256E": 0, "attn_pv_fp8_kernelILi128E": 0,
+                 "proj_fp8_kernel": 1},
+}
+
+
+@pytest.fixture(scope="module")
+def budget_asm(tmp_path_factory):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(_BUDGET)) as ex:                       # (hipcc runs outside the GIL: ~12 s for the five files together)
+        return dict(zip(_BUDGET, ex.map(lambda n: _asm(n, tmp_path_factory), _BUDGET)))
+
+
+@pytest.mark.parametrize("name", sorted(_BUDGET))
+def test_mfma_kernels_keep_two_waves_per_simd_without_spilling(budget_asm, name):
+    lines = budget_asm[name]
+    # each kernel's metadata block lists its keys alphabetically: .name ... .sgpr_spill_count ... .vgpr_count, .vgpr_spill_count ... ; take them per block
+    blocks, cur = [], None
+    for l in lines:
+        if re.match(r"^\s+- \.\w+:", l):              # a new list item of amdhsa.kernels (or of .args: those carry no .name)
+            cur = {}; blocks.append(cur)
+        m = re.match(r"^\s+(?:- )?\.(\w+):\s+(\S+)\s*$", l)
+        if m and cur is not None:
+            cur[m.group(1)] = m.group(2)
+    kernels = {b["name"]: b for b in blocks if "name" in b and "vgpr_count" in b}
+    for sub, max_spill in _BUDGET[name].items():
+        (k, b), = [(k, b) for k, b in kernels.items() if sub in k]
+        assert int(b["vgpr_count"]) <= 256, (k, b["vgpr_count"])
+        assert int(b["vgpr_spill_count"]) <= max_spill and int(b["sgpr_spill_count"]) == 0, (k, b["vgpr_spill_count"], b["sgpr_spill_count"])
