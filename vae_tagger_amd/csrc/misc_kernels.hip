@@ -258,8 +258,13 @@ __global__ __launch_bounds__(256, CONV_IN_OCC) void conv_in_mfma_kernel(const fl
             for (int q = 0; q < 4; ++q) {
                 const int px = q * 4 + (lane >> 4), ch = lane & 15;
                 const u32x4 v4 = *(const u32x4*)(stg + px * 256 + ((ch ^ px) << 4));
-                if (ty < H && tx + px < W)
+                if (ty < H && tx + px < W) {
+#ifdef CONV_IN_NT
+                    __builtin_nontemporal_store(v4, (u32x4*)(outp + ((((long long)b * H + ty) * W + tx + px) * C) * 2 + ch * 16));
+#else
                     *(u32x4*)(outp + ((((long long)b * H + ty) * W + tx + px) * C) * 2 + ch * 16) = v4;
+#endif
+                }
             }
             asm volatile("" ::: "memory");
         }
