@@ -237,3 +237,39 @@ def test_resize_tables_match_the_oracle():
         bounds, kk = R.coefficients(n_in, n_out, kind)
         assert kk.shape[1] == ks and np.array_equal(tab[:, :2], bounds) and np.array_equal(tab[:, 2:], kk), (n_in, n_out, kind)
     assert lib.vt_resize_table(0, 5, 0, None, 0) == -1 and lib.vt_resize_table(5, 5, 2, None, 0) == -1
+
+
+# ---- bench.py's socket-power reader (hwmon): picks the card whose power rose, survives absent files ---------------------------------------------
+def test_bench_socket_power_picks_the_loaded_card_and_tolerates_missing_files(tmp_path, monkeypatch):
+    import glob as _glob
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dirs = []
+    for i, (idle, busy) in enumerate(((250_000_000, 251_000_000), (245_000_000, 1_360_000_000), (None, None))):
+        d = tmp_path / f"card{i}" / "device" / "hwmon" / f"hwmon{i}"
+        d.mkdir(parents=True)
+        if idle is not None:
+            (d / "power1_input").write_text(str(idle))
+            (d / "freq1_input").write_text("150000000")
+            (d / "power1_cap").write_text("1400000000")
+        dirs.append((d, busy))
+    monkeypatch.setattr(_glob, "glob", lambda pat: sorted(str(d) for d, _ in dirs))
+    p = bench.SocketPower()
+    assert p.idle == [250_000_000, 245_000_000, None]
+    for d, busy in dirs:                                   # "the bench starts": card 1 goes to 1360 W at 1.9 GHz
+        if busy is not None:
+            (d / "power1_input").write_text(str(busy))
+            (d / "freq1_input").write_text("1900000000" if busy > 1e9 else "150000000")
+    with p:
+        time.sleep(0.5)
+    s = p.summary()
+    assert s is not None and s["socket_w_median"] == 1360.0 and s["cap_w"] == 1400.0 and s["smu_sclk_mhz_median"] == 1900 and s["samples"] >= 3
+    # no hwmon tree at all (a box that hides it): the bench line carries "power": null
+    monkeypatch.setattr(_glob, "glob", lambda pat: [])
+    q = bench.SocketPower()
+    with q:
+        time.sleep(0.2)
+    assert q.summary() is None
