@@ -429,7 +429,7 @@ def main():
         res = {
             "metric": ("images/sec encode+tag, bucketed 512..1024 bf16" if a.bucketed else
                        "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16").replace(
-                           "bf16", "fp8 (3x3 convs + attention GEMMs; projections, conv_in / conv_out bf16)" if a.fp8 else "bf16").replace(
+                           "bf16", "fp8 (3x3 convs, attention GEMMs, q|k / v projections; to_out, conv_in / conv_out bf16)" if a.fp8 else "bf16").replace(
                            "1024^2", "1024^2" if (a.height, a.width) == (1024, 1024) else f"{a.width}x{a.height}"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_step_without_events": round(elapsed_plain / a.steps * 1e3, 3),
@@ -462,7 +462,7 @@ def main():
         ips8 = B * K2 / e8
         fimg = pipe.flops_per_image(a.height, a.width)
         also["configs4_fp8_per_gpu"] = {
-            "workload": f"configs[4] (per GPU): batch {B}/GPU {a.width}x{a.height} encode+tag, {a.tags} tags, 3x3 convs + Q.K^T / P.V on e4m3 operands (vt_set_flag 11)",
+            "workload": f"configs[4] (per GPU): batch {B}/GPU {a.width}x{a.height} encode+tag, {a.tags} tags, 3x3 convs, q|k / v projections and Q.K^T / P.V on e4m3 operands (vt_set_flag 11)",
             "value": round(ips8, 3), "unit": "images/sec", "steps": K2, "warmup": W2, "ms_per_step": round(e8 / K2 * 1e3, 3), "dtype": "fp8",
             "vt_status": st8, "identical_to_the_batched_result": same8,
             "roofline": {k: roof8[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms", "traffic", "traffic_source", "per_config")},
