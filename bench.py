@@ -436,13 +436,15 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
             "config": cfg, "roofline": roof, "hbm_pass": hbm, "power": power_main,
+            # the figure of merit under the 1400-W cap: socket power of the untraced steps / their images per second
+            "joules_per_image": None if not power_main else round(power_main["socket_w_median"] / (images_per_step / world * a.steps / elapsed_plain), 3),
         }
 
     # ---- the other single-GPU configs of BASELINE.json on the same pipeline, attached to the ONE line as "also" (default run only):
     # configs[4] per GPU (fp8 mode, same batch) and configs[3] (bucketed batches); ~2 s of GPU time, headline keys untouched
     default_run = (world == 1 and not (a.fp8 or a.bucketed or a.encode_only or a.generic_conv or a.no_occ2 or a.flag)
                    and not a.no_also)
-    also_f8_logits = None
+    also_f8_logits = also_f8_idx = None
     if default_run:
         also = {}
         K2, W2 = 10, 2
@@ -469,6 +471,31 @@ def main():
             "hbm_pass": {k: hbm8[k] for k in ("achieved", "frac", "share_of_step")},
             "power": None if power8 is None else {k: power8[k] for k in ("socket_w_median", "cap_w", "smu_sclk_mhz_median", "samples")}}
         also["configs4_fp8_per_gpu"].update(end_to_end(ips8, fimg, fl8_8 / (B * K2)))
+        also["configs4_fp8_per_gpu"]["joules_per_image"] = None if power8 is None else round(power8["socket_w_median"] / ips8, 3)
+        also_f8_idx = pipe.confidence(also_f8_logits)[1]
+        # configs[1]: batch 8, 1024^2, encoder only (vae_model.encode on the VAE mirror's own context), bf16
+        x1 = x[:8] if B >= 8 else x
+        enc_step = lambda: vae_model.encode(x1)
+        for _ in range(W2):
+            enc_step()
+        prof_main, prof_ctx = prof_ctx, vae._context()
+        try:
+            with power:
+                e1, out1, prof1 = timed([enc_step] * K2)
+            power1 = power.summary()
+            st1 = prof_ctx.status()
+        finally:
+            prof_ctx = prof_main
+        assert torch.isfinite(out1).all() and st1 == 0
+        roof1, hbm1, _ = roofline_of(prof1, e1)
+        ips1 = x1.shape[0] * K2 / e1
+        also["configs1_encode_only"] = {
+            "workload": f"configs[1]: batch {x1.shape[0]} {a.width}x{a.height} FLUX-VAE encode only (DiffusersVAEWrapper.encode), bf16",
+            "value": round(ips1, 3), "unit": "images/sec", "steps": K2, "warmup": W2, "ms_per_step": round(e1 / K2 * 1e3, 3), "dtype": "bf16",
+            "roofline": {k: roof1[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms")},
+            "hbm_pass": {k: hbm1[k] for k in ("achieved", "frac", "share_of_step")},
+            "joules_per_image": None if power1 is None else round(power1["socket_w_median"] / ips1, 3)}
+        also["configs1_encode_only"].update(end_to_end(ips1, fimg, 0.0))
         plan3 = make_bucket_plan(W2 + K2)
         for p3 in plan3[:W2]:
             bucket_step(*p3)
@@ -508,6 +535,9 @@ def main():
                 dlg = float(f"{(lg_g.cpu() - ref_lg).abs().max().item():.3e}")
                 res["max_abs_dlogit"] = dlg
                 par["logits_within_tolerance"] = bool(dlg <= tol)
+                # the metric's second half: the HIP path's sorted tag indices (vt_get_confidence on its own logits) against the oracle's order
+                from oracle.agreement import argsort_agreement
+                par["argsort_agreement"] = argsort_agreement(ref_lg[0], lg_g[0], pipe.confidence(lg_g)[1][0])
             if a.fp8:
                 par["latents_within_tolerance"] = None
                 par["latents_note"] = "fp8 mode claims the logits only (north_star's fp8 line); its latents (~1e-1) are out of scope, infer_vae stays bf16"
@@ -518,6 +548,7 @@ def main():
                 d8 = float(f"{(also_f8_logits.cpu() - ref_lg).abs().max().item():.3e}")
                 res["also"]["configs4_fp8_per_gpu"]["max_abs_dlogit"] = d8
                 res["also"]["configs4_fp8_per_gpu"]["logits_within_tolerance"] = bool(d8 <= tol)
+                res["also"]["configs4_fp8_per_gpu"]["argsort_agreement"] = argsort_agreement(ref_lg[0], also_f8_logits[0], also_f8_idx[0])
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -134,3 +134,52 @@ def test_infer_full_and_infer_vae_end_to_end(tmp_path, monkeypatch):
         sure = {t["tag"] for t in want["predicted_tags"] if t["confidence"] > 0.51}
         maybe = {t["tag"] for t in want["predicted_tags"]} | {f"tag_{int(i):05d}" for c, i in zip(conf[0], idx[0]) if c > 0.49}
         assert sure <= got_tags <= maybe
+
+
+@pytest.mark.gpu
+def test_cli_at_configs0_shape_single_512_image(tmp_path):
+    """BASELINE.json configs[0]: infer_full.py on a single 512x512 image, FLUX VAE + 8-head attention decoder (the reference's own
+    CPU-runnable case, infer_full.py:73-141), and infer_vae.py on the same file: latents, confidences and the thresholded tag set
+    against the CPU oracle on the same preprocessed pixels -- what the `encoder_enc_512x512` golden pins for synthetic floats,
+    here through the file -> PIL -> transform -> encode -> decode -> JSON route."""
+    from PIL import Image
+    from safetensors.torch import save_file
+    from oracle import decoder_ref, encoder_ref
+    from vae_tagger_amd.modules import get_image_transform
+    n_tags, res = 1000, 512
+    g = torch.Generator().manual_seed(11)
+    img_path = tmp_path / "one.png"
+    low = torch.rand(16, 16, 3, generator=g)                     # a smooth picture plus noise: not a flat field, not white noise
+    arr = torch.nn.functional.interpolate(low.permute(2, 0, 1)[None], size=(res, res), mode="bicubic", align_corners=False)[0].permute(1, 2, 0)
+    arr = ((arr + 0.08 * torch.randn(res, res, 3, generator=g)).clamp(0, 1) * 255).to(torch.uint8).numpy()
+    Image.fromarray(arr).save(img_path)
+    sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    save_file(sd_e, str(tmp_path / "vae.safetensors"))
+    sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(n_tags), seed=1)
+    torch.save(sd_d, tmp_path / "dec.pth")
+    names = [f"tag_{i:05d}" for i in range(n_tags)]
+    (tmp_path / "tags.csv").write_text("name\n" + "\n".join(names) + "\n")
+    full = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint", str(tmp_path / "dec.pth"),
+                            "--image_path", str(img_path), "--tags_csv_path", str(tmp_path / "tags.csv"), "--output_dir", str(tmp_path / "o"),
+                            "--resolution", str(res)])
+    lat = infer_vae.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--image_path", str(img_path), "--output_dir", str(tmp_path / "o"),
+                          "--resolution", str(res)])
+    assert list(full) == [str(img_path)] == list(lat) and len(lat[str(img_path)]) == 16 * 64 * 64
+    x = get_image_transform(res)(Image.open(img_path).convert("RGB")).unsqueeze(0)
+    ref_lat = encoder_ref.vae_wrapper_encode(sd_e, x)
+    ref_logits = decoder_ref.attention_decoder_forward(sd_d, ref_lat)
+    dl = (torch.tensor(lat[str(img_path)]) - ref_lat.reshape(-1)).abs().max().item()
+    conf, idx = decoder_ref.get_confidence(ref_logits)
+    want = infer_full.summarize(conf[0].tolist(), idx[0].tolist(), names, 0.5)
+    entry = full[str(img_path)]
+    print(f"configs[0] shape through the CLIs: max|dlatent| {dl:.3e}; tags >= 0.5: oracle {want['total_tags_above_threshold']}, HIP {entry['total_tags_above_threshold']}")
+    assert dl <= 1e-2
+    assert abs(entry["max_confidence"] - want["max_confidence"]) <= 2.5e-3        # |dsigmoid| <= |dlogit| / 4
+    assert abs(entry["avg_confidence_top5"] - want["avg_confidence_top5"]) <= 2.5e-3
+    got_tags = {t["tag"] for t in entry["predicted_tags"]}
+    sure = {names[int(i)] for lg, i in zip(ref_logits[0, idx[0]], idx[0]) if lg > 1e-2}
+    maybe = {names[int(i)] for lg, i in zip(ref_logits[0, idx[0]], idx[0]) if lg >= -1e-2}
+    assert sure <= got_tags <= maybe
+    # the written order is the sort order: confidences descending
+    cs = [t["confidence"] for t in entry["predicted_tags"]]
+    assert cs == sorted(cs, reverse=True)

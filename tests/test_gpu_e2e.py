@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import decoder_ref, encoder_ref
+from oracle.agreement import argsort_agreement
 from vae_tagger_amd import synth
 
 from _util import golden, latent_input
@@ -27,6 +28,26 @@ def vae():
     missing, unexpected = m.load_state_dict(synth.synth_state_dict(synth.encoder_manifest(), seed=0), strict=False)
     assert not missing and not unexpected
     return DiffusersVAEWrapper(m).to("cuda").eval()
+
+
+def _check_tag_order(pipe, logits_row, ref_logits_row, what):
+    """The metric's second half (north_star: "bit-exact tag-index argsort"; reference modules.py:470-475 consumed at
+    infer_full.py:106-125): the HIP path's sorted tag indices for one image against the oracle's.  Asserted: identical indices at
+    every rank whose oracle logit is more than 2 x the measured max |dlogit| from both neighbours, every displaced tag inside that
+    band, the thresholded (0.5) tag set equal outside the band, and the device order = (logit desc, index asc) of the device
+    logits exactly.  Printed: the fraction of ranks that could be compared and the first disagreeing rank."""
+    conf, idx = pipe.confidence(logits_row)
+    ag = argsort_agreement(ref_logits_row[0], logits_row[0], idx[0])
+    print(f"{what}: argsort agreement: {ag['ranks_compared']}/{ag['ranks']} ranks comparable at 2 x max|dlogit| {ag['max_abs_dlogit']:.2e} "
+          f"-> identical there: {ag['identical_at_compared_ranks']} (first disagreeing compared rank: {ag['first_disagreeing_compared_rank']}); "
+          f"identical positions overall {ag['frac_identical_positions']:.4f}, first differing rank {ag['first_differing_rank']}, "
+          f"max displacement {ag['max_rank_displacement']}, top-1 / top-5 / top-10 sets same: {ag['top1_identical']} / {ag['top5_set_identical']} / "
+          f"{ag['top10_set_identical']}; tags >= 0.5: oracle {ag['tags_above_threshold_oracle']}, HIP {ag['tags_above_threshold_measured']}")
+    assert ag["identical_at_compared_ranks"], ag
+    assert ag["swaps_stay_inside_the_2d_band"] and ag["threshold_set_matches_outside_the_band"], ag
+    assert torch.equal(idx.cpu(), decoder_ref.get_confidence(logits_row.cpu())[1])
+    assert torch.allclose(conf.cpu(), torch.sigmoid(logits_row.cpu()).gather(1, idx.cpu()), atol=1e-6)
+    return ag
 
 
 def _decoder(n, flags=(True, True, False), plain=False):
@@ -196,6 +217,8 @@ def test_encode_tag_pipeline_matches_oracle(vae):
     ref_logits = decoder_ref.attention_decoder_forward(sd_d, ref_lat)
     assert (lat.cpu() - ref_lat).abs().max().item() <= TOL_LATENT_BF16
     assert (logits.cpu() - ref_logits).abs().max().item() <= 1e-2       # north_star: logits within 1e-2
+    for i in range(3):
+        _check_tag_order(pipe, logits[i:i + 1], ref_logits[i:i + 1], f"128x192 image {i}")
     # same result through the two separate objects (reference call order, infer_full.py:101-102)
     lat2 = vae.encode(x.cuda())
     assert torch.equal(lat2, lat)
@@ -240,6 +263,8 @@ def test_config2_batch16_1024_matches_oracle_across_attention_groups(vae):
         dg = (logits[i:i + 1].cpu() - ref_logits).abs().max().item()
         print(f"configs[2] image {i}: max|dlatent| {dl:.3e} max|dlogit| {dg:.3e}")
         assert dl <= TOL_LATENT_BF16 and dg <= 1e-2, (i, dl, dg)
+        ag = _check_tag_order(pipe, logits[i:i + 1], ref_logits, f"configs[2] image {i}")
+        assert ag["top1_identical"] or ag["max_abs_dlogit"] > 0           # (top-1 is reported; within the band it may legitimately differ)
     # group-boundary / batch-composition invariance, bit for bit
     assert torch.equal(vae.encode(xd[8:9]), lat[8:9])
     assert torch.equal(vae.encode(xd[2:4]), lat[2:4])             # 1 / 2 images: Q.K^T splits each query block's key sweep over 4 / 2 workgroups
@@ -562,6 +587,14 @@ def test_mid_block_attention_on_fp8_operands(gain, S):
         assert torch.isfinite(outs["bf16 kernels"]).all() and not torch.equal(outs["bf16 kernels"], outs["fp8 mode 0"])
         if gain == 1.0:         # (flag 14 off: bf16 q, k, v, P -- the e4m3 rounding of the reference's operands is what shows here)
             assert (outs["bf16 kernels"] - ref).abs().max().item() <= 6e-2
+        # flag 14 off in fp8 mode = the bf16 projections and kernels, for EVERY gain: against fp32 attention of the bf16 operands they multiply
+        qb = bf(x.float() @ bf(sd[A + "to_q.weight"]).t() + sd[A + "to_q.bias"])
+        kb = bf(x.float() @ bf(sd[A + "to_k.weight"]).t() + sd[A + "to_k.bias"])
+        vb = bf(x.float() @ bf(sd[A + "to_v.weight"]).t() + sd[A + "to_v.bias"])
+        ref_b = (torch.softmax(qb @ kb.transpose(1, 2) / C ** 0.5, dim=-1) @ vb) @ bf(sd[A + "to_out.0.weight"]).t() + sd[A + "to_out.0.bias"] + res
+        eb = (outs["bf16 kernels"] - ref_b).abs().max().item()
+        print(f"   flag 14 off (bf16 kernels inside fp8 mode) vs fp32 attention of the bf16 operands: {eb:.3e}")
+        assert eb <= 2e-2
 
 
 def test_evaluation_caller_matches_oracle(vae, tmp_path):
@@ -712,4 +745,87 @@ def test_config4_fp8_batch16_1024_matches_oracle_and_is_batch_invariant(vae):
         dg = (logits[i:i + 1].cpu() - ref_logits).abs().max().item()
         print(f"fp8 batch 16, image {i}: max|dlatent| {dl.abs().max():.3e} rms {dl.pow(2).mean().sqrt():.3e}  max|dlogit| {dg:.3e}")
         assert dg <= 1e-2
+        _check_tag_order(pipe, logits[i:i + 1], ref_logits, f"configs[4] fp8 image {i}")
         assert dl.abs().max().item() <= FP8_LATENT_MAX and dl.pow(2).mean().sqrt().item() <= FP8_LATENT_RMS
+
+
+@pytest.mark.parametrize("res,gain", [(256, 3.0), (256, 6.0), (512, 3.0), (512, 6.0)])
+def test_config4_fp8_with_peaky_attention_rows_through_to_the_logits(res, gain):
+    """fp8 mode on a checkpoint whose mid-block attention rows are dominated by a few keys (to_q / to_k x 3 and x 6: the weights
+    test_mid_block_attention_on_fp8_operands bounds at the operator), through the rest of the encoder and the decoder to the
+    LOGITS, against the oracle run on the same scaled state-dict (the diffusers Attention behind diffusers_vae_loader.py:79).
+    north_star's fp8 line: logits within 1e-2; the status word stays clear; the tag order agrees wherever it is decidable."""
+    from vae_tagger_amd.diffusers_vae_loader import (DiffusersVAEWrapper, get_diffusers_vae_config,
+                                                      load_diffusers_vae_from_config)
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+    n = 10000
+    sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    A = "encoder.mid_block.attentions.0."
+    for k in ("to_q", "to_k"):
+        sd_e[A + k + ".weight"] = sd_e[A + k + ".weight"] * gain
+        sd_e[A + k + ".bias"] = sd_e[A + k + ".bias"] * gain
+    sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(n), seed=1)
+    m = load_diffusers_vae_from_config(get_diffusers_vae_config())
+    m.load_state_dict(sd_e, strict=False)
+    w = DiffusersVAEWrapper(m).to("cuda").eval()
+    pipe = EncodeTagPipeline(w, _decoder(n))
+    x = synth.synth_images(2, res, res, seed=int(gain) * 10 + res)
+    taps = {}
+    ref_lat = encoder_ref.vae_wrapper_encode(sd_e, x)
+    ref_logits = decoder_ref.attention_decoder_forward(sd_d, ref_lat)
+    bf16_logits = pipe.logits(x.cuda())
+    assert pipe.status() == 0
+    try:
+        pipe.set_fp8(True)
+        logits, lat = pipe.logits(x.cuda(), return_latent=True)
+        st = pipe.status()
+        pipe.ctx.call("vt_set_flag", 7, 1)                        # always the exact row maximum
+        logits_exact = pipe.logits(x.cuda())
+        st_exact = pipe.status()
+    finally:
+        pipe.ctx.call("vt_set_flag", 7, 0)
+        pipe.set_fp8(False)
+    dg = (logits.cpu() - ref_logits).abs().max().item()
+    dge = (logits_exact.cpu() - ref_logits).abs().max().item()
+    db = (bf16_logits.cpu() - ref_logits).abs().max().item()
+    dl = lat.cpu() - ref_lat
+    print(f"fp8, to_q/to_k x {gain}, {res}^2: max|dlogit| {dg:.3e} (exact row maximum: {dge:.3e}; bf16 path: {db:.3e}); "
+          f"max|dlatent| {dl.abs().max():.3e} rms {dl.pow(2).mean().sqrt():.3e}; vt_status {st} / {st_exact}")
+    assert st == 0 and st_exact == 0
+    assert db <= 1e-3
+    assert dg <= 1e-2 and dge <= 1e-2
+    for i in range(2):
+        _check_tag_order(pipe, logits[i:i + 1], ref_logits[i:i + 1], f"fp8 peaky x{gain} {res}^2 image {i}")
+
+
+@pytest.mark.parametrize("f15", [1, 0])
+def test_fp8_attention_clamped_v_raises_the_saturation_bit(f15):
+    """|8 v| > 448 cannot be represented in e4m3: with e4m3 projections (flag 15) proj_fp8_kernel raises VT_STATUS_FP8_SATURATED, with bf16
+    projections the v^T conversion pass (attn_vt_to_fp8_kernel) does -- a clamped attention is never returned silently."""
+    import ctypes
+    from vae_tagger_amd._lib import VT_STATUS_FP8_SATURATED
+    from vae_tagger_amd.diffusers_vae_loader import get_diffusers_vae_config, load_diffusers_vae_from_config
+    from _util import vp
+    sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    A = "encoder.mid_block.attentions.0."
+    sd[A + "to_v.bias"] = sd[A + "to_v.bias"] + 80.0
+    m = load_diffusers_vae_from_config(get_diffusers_vae_config())
+    m.load_state_dict(sd, strict=False)
+    ctx = m.to("cuda").eval()._context()
+    B, S, C = 1, 200, 512
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, S, C, generator=g).bfloat16().cuda()
+    res = torch.randn(B, S, C, generator=g).cuda()
+    ws = torch.empty(ctx.lib.vt_op_attention_workspace_bytes(B, S, C), dtype=torch.uint8, device="cuda")
+    out = torch.empty(B, S, C, device="cuda")
+    try:
+        ctx.call("vt_set_flag", 11, 1)
+        ctx.call("vt_set_flag", 15, f15)
+        ctx.call("vt_op_attention", vp(x), vp(res), vp(out), B, S, C, vp(ws), ctypes.c_void_p(0))
+        assert ctx.status() == VT_STATUS_FP8_SATURATED and ctx.status() == 0
+        ctx.call("vt_set_flag", 11, 0)
+        ctx.call("vt_op_attention", vp(x), vp(res), vp(out), B, S, C, vp(ws), ctypes.c_void_p(0))
+        assert ctx.status() == 0 and torch.isfinite(out).all()
+    finally:
+        ctx.call("vt_set_flag", 15, 1)
+        ctx.call("vt_set_flag", 11, 0)

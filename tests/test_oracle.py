@@ -100,3 +100,39 @@ def test_resize_restatement_matches_pillow_bit_for_bit():
     assert R.smart_crop_box(400, 200, 512, 512) == (100, 0, 200, 200)
     assert R.smart_crop_box(200, 400, 512, 512) == (0, 100, 200, 200)
     assert R.smart_crop_box(300, 300, 640, 640) == (0, 0, 300, 300)
+
+
+def test_argsort_agreement_definition():
+    """oracle/agreement.py (the metric's second half, reference modules.py:470-475 as consumed at infer_full.py:106-125): a
+    perturbation of the logits inside +-d can only reorder tags whose oracle logits are within 2 d of each other, so the
+    must-hold parts of the report hold by construction; a defect outside the band (two well-separated tags swapped in the
+    index array, a tag dropped from the thresholded set) is caught."""
+    from oracle.agreement import argsort_agreement
+    g = torch.Generator().manual_seed(0)
+    n = 10000
+    ref = 0.4 * torch.randn(n, generator=g)
+    for d in (2e-4, 5e-3):
+        got = ref + d * (2 * torch.rand(n, generator=g) - 1)
+        idx = decoder_ref.get_confidence(got[None])[1][0]
+        a = argsort_agreement(ref, got, idx)
+        assert a["identical_at_compared_ranks"] and a["swaps_stay_inside_the_2d_band"] and a["threshold_set_matches_outside_the_band"]
+        assert 0 < a["ranks_compared"] < n and a["frac_identical_positions"] < 1.0 and a["top1_identical"] in (True, False)
+        assert a["max_abs_dlogit"] <= d
+    same = argsort_agreement(ref, ref, decoder_ref.get_confidence(ref[None])[1][0])
+    assert same["frac_identical_positions"] == 1.0 and same["ranks_compared"] > 0.9 * n and same["max_rank_displacement"] == 0
+    # a sort defect: the two top tags (far apart in the tail) exchanged
+    got = ref + 2e-4 * (2 * torch.rand(n, generator=g) - 1)
+    idx = decoder_ref.get_confidence(got[None])[1][0].clone()
+    idx[[0, 40]] = idx[[40, 0]]
+    a = argsort_agreement(ref, got, idx)
+    assert not a["swaps_stay_inside_the_2d_band"] and not a["identical_at_compared_ranks"] and a["first_disagreeing_compared_rank"] == 0
+    # a logit defect outside the tolerance on one tag shows in the thresholded set when d is stated by the caller
+    got = ref.clone()
+    k = int(torch.argmax((ref > 0.05).float()))
+    got[k] = -1.0
+    a = argsort_agreement(ref, got, decoder_ref.get_confidence(got[None])[1][0], max_abs_dlogit=1e-2)
+    assert not a["threshold_set_matches_outside_the_band"]
+    # ties: equal oracle logits are never "compared", and ascending index is the defined order
+    tie = torch.tensor([0.5, 0.5, -1.0, 2.0])
+    a = argsort_agreement(tie, tie, torch.tensor([3, 0, 1, 2]))
+    assert a["frac_identical_positions"] == 1.0 and a["ranks_compared"] == 2

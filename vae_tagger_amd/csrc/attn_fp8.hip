@@ -479,12 +479,13 @@ __global__ __launch_bounds__(512, 2) void attn_pv_fp8_kernel(const AttnPv8Args a
 
 // v^T bf16 [C][ldv] -> e4m3(scale v^T) [C][ld8]; keys >= S are written as zero up to kext (a multiple of 16)
 __global__ __launch_bounds__(256) void attn_vt_to_fp8_kernel(const bf16_t* __restrict__ vt, long long vt_bs, int ldv, unsigned char* __restrict__ v8,
-                                                             long long v8_bs, int ld8, int S, int kext, int C, float scale) {
+                                                             long long v8_bs, int ld8, int S, int kext, int C, float scale, int* __restrict__ status) {
     const int b = blockIdx.z, ch = blockIdx.y;
     const int k0 = (blockIdx.x * 256 + threadIdx.x) * 16;
     if (k0 >= kext) return;
     const bf16_t* src = vt + (long long)b * vt_bs + (long long)ch * ldv + k0;
     i32x4 o = {0, 0, 0, 0};
+    float big = 0.f;                                           // largest |scale v| converted: beyond 448 the e4m3 value is a clamp (status bit 1)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         float f[8];
@@ -497,13 +498,14 @@ __global__ __launch_bounds__(256) void attn_vt_to_fp8_kernel(const bf16_t* __res
             for (int r = 0; r < 8; ++r) f[r] = 0.f;
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) f[r] = __builtin_amdgcn_fmed3f(f[r], -448.f, 448.f);
+        for (int r = 0; r < 8; ++r) { big = fmaxf(big, fabsf(f[r])); f[r] = __builtin_amdgcn_fmed3f(f[r], -448.f, 448.f); }
         int w0 = 0, w1 = 0;
         w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
         w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
         o[2 * hh] = w0; o[2 * hh + 1] = w1;
     }
     *(i32x4*)(v8 + (long long)b * v8_bs + (long long)ch * ld8 + k0) = o;
+    if (status && !(big <= 448.f)) atomicOr(status, 2);        // (NaN counts: it was turned into +-448 by the clamp)
 }
 
 }  // namespace
@@ -572,9 +574,9 @@ hipError_t vt_launch_attn_pv_fp8(const AttnPv8Args& a, hipStream_t s) {
 }
 
 hipError_t vt_launch_attn_vt_to_fp8(const bf16_t* vt, long long vt_bs, int ldv, unsigned char* v8, long long v8_bs, int ld8, int S, int kext,
-                                    int C, int batch, float scale, hipStream_t s) {
+                                    int C, int batch, float scale, int* status, hipStream_t s) {
     if (!vt || !v8 || S <= 0 || C <= 0 || batch <= 0 || (kext % 16) || kext > ld8 || (ld8 % 16) || (ldv % 8)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(attn_vt_to_fp8_kernel, dim3((unsigned)((kext / 16 + 255) / 256), (unsigned)C, (unsigned)batch), dim3(256), 0, s, vt, vt_bs, ldv, v8,
-                       v8_bs, ld8, S, kext, C, scale);
+                       v8_bs, ld8, S, kext, C, scale, status);
     return hipGetLastError();
 }

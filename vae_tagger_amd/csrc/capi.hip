@@ -763,7 +763,7 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
         HIPCK(c, vt_launch_attn_row_norms(sc.qk, (long long)B * S, C, sc.qn, sc.kn, sc.sd, s), "attn row norms");
         HIPCK(c, vt_launch_attn_shift(sc.qn, sc.kn, sc.sd, B, S, scale, 120.f, sc.shift, sc.flags, sc.group, s), "attn shift");
     }
-    if (f8 && !p8) HIPCK(c, vt_launch_attn_vt_to_fp8(sc.vt, (long long)C * lp, lp, sc.vt8, (long long)C * ld8, ld8, S, kext8, C, B, FP8_QK_SCALE, s), "attn v^T fp8");
+    if (f8 && !p8) HIPCK(c, vt_launch_attn_vt_to_fp8(sc.vt, (long long)C * lp, lp, sc.vt8, (long long)C * ld8, ld8, S, kext8, C, B, FP8_QK_SCALE, c->status, s), "attn v^T fp8");
     for (int b0 = 0; b0 < B; b0 += sc.group) {
         const int nb = (B - b0 < sc.group) ? B - b0 : sc.group;
         const bf16_t* q = sc.qk + (long long)b0 * S * 2 * C;

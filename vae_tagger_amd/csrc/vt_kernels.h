@@ -148,7 +148,7 @@ long long vt_attn_p8_bytes(int S);
 hipError_t vt_launch_attn_qk_fp8(const AttnQk8Args& a, hipStream_t s);
 hipError_t vt_launch_attn_pv_fp8(const AttnPv8Args& a, hipStream_t s);
 hipError_t vt_launch_attn_vt_to_fp8(const bf16_t* vt, long long vt_bs, int ldv, unsigned char* v8, long long v8_bs, int ld8, int S, int kext,
-                                    int C, int batch, float scale, hipStream_t s);
+                                    int C, int batch, float scale, int* status, hipStream_t s);
 // row norms of q | k as attn_row_norms, taken from the e4m3(scale x) values this kernel also writes (qk8: [rows][2C] bytes)
 hipError_t vt_launch_attn_row_norms_fp8(const bf16_t* qk, long long rows, int C, float scale, unsigned char* qk8, float* qn, float* kn, float* sd,
                                         int* status, hipStream_t s);
