@@ -154,6 +154,10 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  * flag 15: 1 (default) = with flag 14, the q | k and v projections multiply e4m3 operands too (tokens e4m3(8 x) from the GroupNorm pass,
  *         [Wq; Wk] and Wv as e4m3(W / s), one scale per matrix) and write q8 | k8 and v8^T directly (proj_fp8_kernel); 0 = bf16
  *         projections followed by conversion passes.
+ * flag 16: tile shape of the fp8 halo conv (flag 11) = value & 3: 0 (default) = 8 rows x 32 px x 128 couts on 4 waves, two workgroups
+ *         per CU; 1 = 16 x 32 px, 2 = 8 x 64 px, both on 8 waves, one workgroup per CU (a staged weight tile serves twice the pixels);
+ *         applied to the layers with Cin <= 128, or to every layer with value & 4.  The conv outputs are bit-identical for every value (the
+ *         GroupNorm partials are per tile, so their merge order -- the last bits of the statistics -- follows the shape).
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

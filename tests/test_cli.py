@@ -172,8 +172,17 @@ def test_cli_at_configs0_shape_single_512_image(tmp_path):
     conf, idx = decoder_ref.get_confidence(ref_logits)
     want = infer_full.summarize(conf[0].tolist(), idx[0].tolist(), names, 0.5)
     entry = full[str(img_path)]
-    print(f"configs[0] shape through the CLIs: max|dlatent| {dl:.3e}; tags >= 0.5: oracle {want['total_tags_above_threshold']}, HIP {entry['total_tags_above_threshold']}")
-    assert dl <= 1e-2
+    # A SMOOTH picture is harder for 8-bit significands than the uniform noise of the synthetic batches: where the picture is flat the
+    # rounding errors of neighbouring pixels are equal, so a 3x3 conv adds them coherently instead of averaging them.  The oracle with its
+    # operands rounded to bf16 (encoder_ref's emulate_bf16: the arithmetic north_star prescribes) is itself 1.5e-2 from the fp32 oracle on
+    # this image (7e-3 on noise of the same size; rms 1.7e-3 vs 1.6e-3) -- the bar for the latent MAXIMUM here is that emulation, not 1e-2;
+    # rms, confidences and the tag set keep their bounds.  (fp16 operands would give 1.5e-3: tests/diagnostics/smooth_image_study.py.)
+    emu = encoder_ref.vae_wrapper_encode(sd_e, x, emulate_bf16=True)
+    d_emu = (emu - ref_lat).abs().max().item()
+    rms = (torch.tensor(lat[str(img_path)]) - ref_lat.reshape(-1)).pow(2).mean().sqrt().item()
+    print(f"configs[0] shape through the CLIs: max|dlatent| {dl:.3e} (bf16-operand emulation of the oracle: {d_emu:.3e}), rms {rms:.3e}; "
+          f"tags >= 0.5: oracle {want['total_tags_above_threshold']}, HIP {entry['total_tags_above_threshold']}")
+    assert dl <= max(1e-2, 1.5 * d_emu) and rms <= 3e-3
     assert abs(entry["max_confidence"] - want["max_confidence"]) <= 2.5e-3        # |dsigmoid| <= |dlogit| / 4
     assert abs(entry["avg_confidence_top5"] - want["avg_confidence_top5"]) <= 2.5e-3
     got_tags = {t["tag"] for t in entry["predicted_tags"]}

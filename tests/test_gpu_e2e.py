@@ -388,6 +388,34 @@ def test_config4_fp8_operands_keep_the_logits_within_tolerance(vae, res):
     assert (bf16_logits.cpu() - ref_logits).abs().max().item() <= 1e-3
 
 
+@pytest.mark.parametrize("shape", [1, 2, 5, 6])
+def test_config4_fp8_tile_shapes_through_the_encoder(vae, shape):
+    """vt_set_flag(ctx, 16, shape): the 8-wave tiles of the fp8 halo conv inside the whole path (GroupNorm partials per tile, fp16 residual
+    staging of eight waves, the fused shortcut on layers with Cin > 128 for shape | 4), ragged 100 x 148 and whole-tile 128 x 192 inputs:
+    logits within 1e-2 of the oracle, deterministic, and -- the conv outputs being bit-identical, only the merge order of the GroupNorm
+    partials differs -- within 1e-4 of the default tile's logits."""
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+    n = 1000
+    pipe = EncodeTagPipeline(vae, _decoder(n))
+    sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(n), seed=1)
+    for (hh, ww) in ((100, 148), (128, 192)):
+        x = synth.synth_images(2, hh, ww, seed=hh + shape)
+        ref_logits = decoder_ref.attention_decoder_forward(sd_d, encoder_ref.vae_wrapper_encode(sd_e, x))
+        try:
+            pipe.set_fp8(True)
+            base = pipe.logits(x.cuda())
+            pipe.ctx.call("vt_set_flag", 16, shape)
+            logits = pipe.logits(x.cuda())
+            again = pipe.logits(x.cuda())
+        finally:
+            pipe.ctx.call("vt_set_flag", 16, 0)
+            pipe.set_fp8(False)
+        assert pipe.status() == 0 and torch.equal(again, logits)
+        assert (logits.cpu() - ref_logits).abs().max().item() <= 1e-2
+        assert (logits - base).abs().max().item() <= 1e-4
+
+
 @pytest.mark.parametrize("h,w,b", [(72, 88, 2), (100, 76, 1), (576, 768, 2), (1024, 512, 1)])
 def test_config4_fp8_on_ragged_and_bucket_shapes(vae, h, w, b):
     """fp8 mode on shapes that are not multiples of its 8 x 32 pixel tile (ragged tiles in every stage, odd sizes into the

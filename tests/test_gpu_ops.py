@@ -257,6 +257,28 @@ def test_fp8_conv_matches_torch_on_the_same_quantised_operands(ops, B, Cin, Cout
     assert torch.allclose(got, ref_of(x), rtol=1e-4, atol=3e-3), (got - ref_of(x)).abs().max()
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", FP8_CASES + [(1, 128, 128, 37, 131), (2, 128, 256, 16, 64)])
+def test_fp8_conv_tile_shapes_are_bit_identical(ops, B, Cin, Cout, H, W):
+    """vt_set_flag(ctx, 16, v): the fp8 halo conv on 16 x 32 px (1) and 8 x 64 px (2) tiles of 8 waves instead of 8 x 32 px on 4 waves --
+    the same K-step order per output pixel, so the results are the default tile's bit for bit (ragged edges, images smaller than a tile,
+    several cout tiles, with and without residual); + 4 applies the shape to layers with Cin > 128 too."""
+    x = _rand((B, Cin, H, W), 11)
+    w = _rand((Cout, Cin, 3, 3), 12, (Cin * 9) ** -0.5)
+    b = _rand((Cout,), 13, 0.1)
+    res = _rand((B, Cout, H, W), 14)
+    base = ops.conv3x3_fp8(x, w, b, residual_nchw=res)
+    base_plain = ops.conv3x3_fp8(x, w)
+    try:
+        for v in (5, 6):
+            ops.ctx.call("vt_set_flag", 16, v)
+            assert torch.equal(ops.conv3x3_fp8(x, w, b, residual_nchw=res), base), v
+            assert torch.equal(ops.conv3x3_fp8(x, w), base_plain), v
+    finally:
+        ops.ctx.call("vt_set_flag", 16, 0)
+    with pytest.raises(Exception):
+        ops.ctx.call("vt_set_flag", 16, 3)
+
+
 def test_fp8_mfma_block_sum_keeps_a_bounded_window_below_its_largest_product(ops):
     """Isolates what the saturated case above tolerates (atol 3e-3): v_mfma_scale_f32_32x32x64_f8f6f4 does not add the 64 products
     of a K-block in fp32 -- it aligns them to the block's LARGEST product and keeps a bounded number of bits below it.

@@ -93,7 +93,7 @@ def test_attention_lds_reads_are_ahead_of_their_mfmas(attention_asm, kernel):
 # CPU, instead of as a few per cent on the GPU.
 _BUDGET = {  # file: {kernel substring: max vgpr_spill_count}
     "conv3x3_halo": {"conv3x3_halo_kernelILi2ELi2ELi0ELi8ELi4E": 0},
-    "conv3x3_halo_fp8": {"conv3x3_halo_fp8_kernel": 0},
+    "conv3x3_halo_fp8": {"conv3x3_halo_fp8_kernelILi2ELi1E": 0, "conv3x3_halo_fp8_kernelILi4ELi1E": 0, "conv3x3_halo_fp8_kernelILi2ELi2E": 0},
     "conv3x3_s2_halo": {"conv3x3_s2_halo_kernel": 3},            # three, in the last chunk's epilogue hand-over, none in the steady-state loop
     "conv3x3_s2_halo_fp8": {"conv3x3_s2_halo_fp8_kernel": 0},
     "attn_fp8": {"attn_qk_fp8_kernelILi1E": 0, "attn_qk_fp8_kernelILi3E": 0, "attn_pv_fp8_kernelILi256E": 0, "attn_pv_fp8_kernelILi128E": 0,

@@ -22,7 +22,7 @@ def run8(B, H, W, Cin, Cout, iters=8):
     ctx.call("vt_profile_begin")
     for _ in range(iters): call()
     ctx.call("vt_profile_end", ns, la, ms, fl, nm)
-    i = [k for k in range(ns) if nm[k] and b"halo_fp8" in nm[k]][0]
+    i = max((k for k in range(ns) if nm[k] and b"halo_fp8" in nm[k]), key=lambda k: la[k])       # (Cin <= 128 launches have a slot of their own)
     t = ms[i] / la[i]
     tiles = B * (H // 8) * (W // 32) * (Cout // 128)
     us_tile = t * 1e3 / (tiles / 512.0)                       # two workgroups per CU

@@ -57,7 +57,7 @@ def run8(B, H, W, Cin, Cout, fill, iters=10):
     ctx.call("vt_profile_begin")
     for _ in range(iters): call()
     ctx.call("vt_profile_end", ns, la, ms, fl, nm)
-    i = [k for k in range(ns) if nm[k] and b"fp8" in nm[k]][0]
+    i = max((k for k in range(ns) if nm[k] and b"fp8" in nm[k]), key=lambda k: la[k])       # (Cin <= 128 launches have a slot of their own)
     print(f"fp8 {fill:8s} B{B} {H}x{W} {Cin}->{Cout}: {ms[i] / la[i]:7.3f} ms  {fl[i] / ms[i] / 1e9:7.1f} TFLOP/s", flush=True)
 for shape in ((16, 512, 512, 256, 256), (8, 1024, 1024, 128, 128), (16, 256, 256, 512, 512), (8, 512, 512, 1024, 256)):
     for fill in ("random", "zeros", "random"):

@@ -23,6 +23,6 @@ for (B, H, W, Cin, Cout) in ((16, 1024, 1024, 128, 128), (16, 512, 512, 256, 256
     ctx.call("vt_profile_begin")
     for _ in range(60): call()
     ctx.call("vt_profile_end", ns, la, ms, fl, nm)
-    i = [k for k in range(ns) if nm[k] and b"halo_fp8" in nm[k]][0]
+    i = max((k for k in range(ns) if nm[k] and b"halo_fp8" in nm[k]), key=lambda k: la[k])       # (Cin <= 128 launches have a slot of their own)
     print(f"{name:22s} fp8 {Cin:4d}->{Cout:4d} @{H:4d}^2: {ms[i] / la[i]:7.3f} ms {fl[i] / ms[i] / 1e9:7.1f} TFLOP/s", flush=True)
     del x, w, out, ws

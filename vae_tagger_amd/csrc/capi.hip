@@ -151,6 +151,8 @@ struct vt_context {
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
     int proj_fp8 = 1;               // vt_set_flag(ctx, 15, v): with the fp8 attention, the q | k and v projections on e4m3 operands too, writing q8 | k8 and v8^T directly
     int attn_fp8 = 1;               // vt_set_flag(ctx, 14, v): in fp8 mode (flag 11) Q.K^T and P.V run on e4m3 operands too (attn_fp8.hip)
+    int fp8_tile = 0;               // vt_set_flag(ctx, 16, v): fp8 halo conv tile shape = v & 3 (0: 8 x 32 px, 4 waves, two workgroups per CU; 1: 16 x 32 px;
+                                    // 2: 8 x 64 px, 8 waves, one per CU) on the layers with Cin <= 128, or on every layer with v & 4
     int s2_halo = 1;                // vt_set_flag(ctx, 13, v): stride-2 convs on the phase-plane halo kernel instead of the generic GEMM
     // vt_resize_u8: pinned staging of the coefficient tables + the event of the last H2D copy that read it
     int* rs_host = nullptr; size_t rs_host_ints = 0; hipEvent_t rs_event = nullptr;
@@ -408,7 +410,7 @@ hipError_t launch_halo_fp8(vt_context* c, const Conv3x3Fp8Args& a, hipStream_t s
     r.e0 = c->next_event(); r.e1 = c->next_event();
     if (!r.e0 || !r.e1) return hipErrorOutOfMemory;
     r.flops = 2.0 * a.batch * (double)a.H * a.W * a.Cout * (9.0 * a.Cin + (a.scX ? a.scCin : 0));
-    r.cfg = VT_PROF_HALO_FP8;
+    r.cfg = a.Cin <= 128 ? VT_PROF_HALO_FP8_C128 : VT_PROF_HALO_FP8;
     hipError_t e = hipEventRecord(r.e0, s);
     if (e != hipSuccess) return e;
     e = vt_launch_conv3x3_halo_fp8(a, s);
@@ -525,7 +527,8 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
         if (o16_e4m3) { h.out_e4m3 = (unsigned char*)o16; h.out_e4m3_scale = FP8_RES_SCALE; h.status = c->status; }
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
         if (sc) { h.scX = sc->x; h.scW = sc->wp8; h.scCin = sc->cin; h.bias = sc->bias; }
-        if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_fp8_tiles(Hin, Win); }
+        h.shape = (w.cin <= 128 || (c->fp8_tile & 4)) ? (c->fp8_tile & 3) : 0;
+        if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_fp8_tiles_shape(Hin, Win, h.shape); }
         HIPCK(c, launch_halo_fp8(c, h, s), "conv3x3_halo_fp8");
         return VT_OK;
     }
@@ -1504,6 +1507,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 9) { c->attn_qk_kernel = value != 0; return VT_OK; }
     if (flag == 10) { c->pv_stream = value != 0; return VT_OK; }
     if (flag == 11) { c->fp8 = value != 0; return VT_OK; }
+    if (flag == 16) { if ((value & 3) == 3 || value < 0 || value > 7) return c->fail(VT_ERR_INVALID, "vt_set_flag(16): tile shape 0..2 (+4: every layer)"); c->fp8_tile = value; return VT_OK; }
     if (flag == 12) { c->attn_pv_kernel = value != 0; return VT_OK; }
     if (flag == 13) { c->s2_halo = value != 0; return VT_OK; }
     if (flag == 14) { c->attn_fp8 = value != 0; return VT_OK; }
@@ -1825,6 +1829,7 @@ int vt_op_conv3x3_fp8(vt_context* c, const float* x_nhwc, const float* w_oihw, c
     Conv3x3Fp8Args h{};
     h.X = x8; h.Wp = w8; h.mult = mult; h.bias = bias; h.res = res; h.out_f32 = o32; h.zeros = c->zeros;
     h.batch = B; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout;
+    h.shape = (Cin <= 128 || (c->fp8_tile & 4)) ? (c->fp8_tile & 3) : 0;
     HIPCK(c, launch_halo_fp8(c, h, s), "vt_op_conv3x3_fp8");
     return VT_OK;
 }

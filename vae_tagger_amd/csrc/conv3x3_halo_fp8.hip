@@ -58,22 +58,35 @@ extern "C" int vt_debug_halo_fp8_stamps(unsigned long long* buf, int H, int Cin,
 namespace {
 
 constexpr int HB = 64;                       // bytes per LDS row
-constexpr int TWX = 32;                      // tile width in pixels = N of the MFMA
-constexpr int HWID = TWX + 2;                // halo width
-constexpr int WP = 2, WC = 2, TP = 4;        // waves: pixel-row groups x cout groups; rows per wave
-constexpr int ROWS = WP * TP;                // 8 tile rows
+constexpr int WC = 2, TP = 4;                // cout wave groups (x 64 couts); tile rows per wave
 constexpr int BC = WC * 64;                  // 128 couts per workgroup
-constexpr int NWV = WP * WC, NT = 64 * NWV;
-constexpr int HROWS = (ROWS + 2) * HWID;     // 340 halo pixels
-constexpr int NXW = ((HROWS + 15) / 16 + NWV - 1) / NWV;      // X pieces (16 rows each) per wave: 6
-constexpr int XBUF = NXW * NWV * 16 * HB;    // 24 KB per halo buffer
 constexpr int WPCS = BC / 16;                // W pieces per K-step: 8
-constexpr int WPW = WPCS / NWV;              // ... per wave: 2
 constexpr int WBUF = BC * HB;                // 8 KB per stage
 constexpr int NW = 4;                        // weight ring depth
 constexpr int LEAD = NW - 1;                 // W(t + LEAD) is issued during step t (two barriers after the stage's last read)
 constexpr int WOUT = LEAD - 2;               // W tiles issued after the one a barrier needs (fragments of t+1 are read during t)
-constexpr int SMEM = 2 * XBUF + NW * WBUF;   // 80 KB
+
+// Tile shape = (WP x TP) rows x (WX x 32) pixels x 128 couts on WP x WX x 2 waves; a wave's tile is always 4 rows x 32 px x 64 couts.
+//   <2, 1>: 8 x 32 px, 4 waves, 80 KB LDS, two workgroups per CU (the default);
+//   <4, 1>: 16 x 32 px, 8 waves, one workgroup per CU: one staged weight tile serves twice the pixels, halo over-read 1.19x instead of 1.33x;
+//   <2, 2>: 8 x 64 px, 8 waves, one workgroup per CU (over-read 1.29x).  vt_set_flag(ctx, 16, shape); round-4 A/B: profiles/r04/halo_fp8_tile_shapes_ab.log
+template <int WP_, int WX_>
+struct Shape {
+    static constexpr int WP = WP_, WX = WX_;
+    static constexpr int TWX = 32 * WX;                  // tile width in pixels (the MFMA's N = 32 per wave)
+    static constexpr int HWID = TWX + 2;                 // halo width
+    static constexpr int ROWS = WP * TP;                 // tile rows
+    static constexpr int NWV = WP * WX * WC, NT = 64 * NWV;
+    static constexpr int HROWS = (ROWS + 2) * HWID;      // halo pixels
+    static constexpr int NXW = ((HROWS + 15) / 16 + NWV - 1) / NWV;      // X pieces (16 rows each) per wave
+    static constexpr int XBUF = NXW * NWV * 16 * HB;     // bytes per halo buffer
+    static constexpr int WPW = WPCS / NWV;               // W pieces per wave and K-step
+    static constexpr int SMEM_LOOP = 2 * XBUF + NW * WBUF;
+    static constexpr int SMEM_RES = NWV * 16384 + WBUF;  // epilogue: a 16-KB fp16 residual tile per wave + the GroupNorm scratch behind them
+    static constexpr int SMEM = SMEM_LOOP > SMEM_RES ? SMEM_LOOP : SMEM_RES;
+    static constexpr int WG_PER_CU = SMEM <= 80 * 1024 ? 2 : 1;
+    static_assert(WPCS % NWV == 0 && SMEM <= 160 * 1024, "tile shape");
+};
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -99,13 +112,17 @@ __device__ __forceinline__ i32x8 read_frag(const char* base, int row, int g) {
     return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-__global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp8Args a) {
+template <int WP, int WX>
+__global__ __launch_bounds__(64 * WP * WX * WC, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp8Args a) {
+    typedef Shape<WP, WX> SH;
+    constexpr int TWX = SH::TWX, HWID = SH::HWID, ROWS = SH::ROWS, NWV = SH::NWV, HROWS = SH::HROWS, NXW = SH::NXW, XBUF = SH::XBUF,
+                  WPW = SH::WPW, SMEM = SH::SMEM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xbase = smem;                    // 2 halo buffers
     char* const wbase = smem + 2 * XBUF;         // NW weight stages
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wp = wave / WC, wc = wave % WC;
+    const int wc = wave % WC, wx = (wave / WC) % WX, wp = wave / (WC * WX);
     const int g = lane >> 5, li = lane & 31;
     STAMP(0);
 
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
 
     // fragment rows: W stage row wc*64 + 32 h + li; X halo row (wp*TP + r) * HWID + dx + li
     const int wrow0 = wc * 64 + li;
-    const int xrow0 = wp * TP * HWID + li;
+    const int xrow0 = wp * TP * HWID + wx * 32 + li;
     i32x8 wfc[2], xr[TP + 2];
     {
         int ahead0 = nk - 1;
@@ -276,10 +293,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                        // the staging buffers are free
             asm volatile("" ::: "memory");
+            static_assert(ROWS * TWX / 16 == 4 * NWV, "shortcut staging: 4 pieces per wave");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {                        // the tile's 8 x 32 pixels, 16 per piece, 4 pieces per wave
+            for (int j = 0; j < 4; ++j) {                        // the tile's ROWS x TWX pixels, 16 per piece, 4 pieces per wave
                 const int pp = (j * NWV + wave) * 16 + drow;
-                const int iy = ty0 + (pp >> 5), ix = tx0 + (pp & 31);
+                const int iy = ty0 + pp / TWX, ix = tx0 + pp % TWX;
                 const void* src = (iy < a.H && ix < a.W) ? (const void*)(Xs + ((long long)(iy * a.W + ix) * a.scCin + c * 32 + dchunk * 8)) : a.zeros;
                 __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(xbase + (j * NWV + wave) * 1024), 16, 0, 0);
             }
@@ -301,7 +319,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
                 }
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
-                    const int row = (wp * TP + j) * 32 + li;
+                    const int row = (wp * TP + j) * TWX + wx * 32 + li;
                     const bf16x8 xf = *(const bf16x8*)(xbase + row * HB + (((2 * ks + g) ^ swz(row)) << 4));
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
@@ -321,7 +339,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
     // ---- epilogue: register r of lane (g, x = li) in acc[h][j] is cout cw(h) + r of pixel (ty0 + wp*TP + j, tx0 + li)
     const int HWp = a.H * a.W;
     const long long ob = (long long)b * HWp * a.Cout;
-    const int x = tx0 + li;
+    const int x = tx0 + wx * 32 + li;
     // fp16 residual: fetched with ONE LDS-DMA burst per wave (its own 4 rows x 32 px x 64 couts = 16 KB, into the staging
     // buffers the main loop no longer needs) instead of eight dependent global-load round trips inside the store loop.
     // Piece p of a wave = pixels 8 p .. 8 p + 7 of its region x 128 B; lane l -> pixel (l >> 3), physical 16-B chunk (l & 7),
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
 #pragma unroll 4
         for (int pc = 0; pc < 16; ++pc) {
             const int pp = pc * 8 + (lane >> 3);
-            const int yy = ty0 + wp * TP + (pp >> 5), xx = tx0 + (pp & 31);
+            const int yy = ty0 + wp * TP + (pp >> 5), xx = tx0 + wx * 32 + (pp & 31);
             const int lc = (lane & 7) ^ (pp & 7);
             const void* src = (yy < a.H && xx < a.W)
                 ? (const void*)(a.res_f16 + ob + ((long long)yy * a.W + xx) * a.Cout + c0 + wc * 64 + lc * 8) : a.zeros;
@@ -493,7 +511,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
                     for (int q = 0; q < NQ; ++q) {
                         const float ms = s[h][q] * rn;
                         const int lg = (wc * 64 + 32 * h + 16 * g + q * CPG) / CPG;
-                        float* d = lds + (wp * gpb + lg) * 3;
+                        float* d = lds + ((wp * WX + wx) * gpb + lg) * 3;
                         d[0] = n; d[1] = n > 0.f ? piv[h][q] + ms : 0.f; d[2] = n > 0.f ? fmaxf(ss[h][q] - s[h][q] * ms, 0.f) : 0.f;
                     }
             }
@@ -508,12 +526,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if ((int)threadIdx.x < gpb) {
-            static_assert(WP == 2, "two pixel-row waves are merged");
-            const float* d0 = lds + threadIdx.x * 3;
-            const float* d1 = lds + (gpb + threadIdx.x) * 3;
             float nn = 0.f, mean = 0.f, m2 = 0.f;
-            vt_chan_merge(nn, mean, m2, d0[0], d0[1], d0[2]);
-            vt_chan_merge(nn, mean, m2, d1[0], d1[1], d1[2]);
+#pragma unroll
+            for (int pw = 0; pw < WP * WX; ++pw) {               // the pixel-wave groups, in a fixed order
+                const float* d = lds + (pw * gpb + threadIdx.x) * 3;
+                vt_chan_merge(nn, mean, m2, d[0], d[1], d[2]);
+            }
             const int G = a.Cout / cpg;
             float* o = a.gn_partial + (((long long)b * a.ptiles + tile) * G + c0 / cpg + threadIdx.x) * 3;
             o[0] = nn; o[1] = mean; o[2] = m2;
@@ -535,13 +553,38 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_fp8_kernel(const Conv3x3Fp
 }  // namespace
 
 bool vt_conv3x3_halo_fp8_supported(int Cin, int Cout) { return Cin >= 64 && (Cin % 64) == 0 && (Cout % 128) == 0; }
-int vt_conv3x3_halo_fp8_tiles(int H, int W) { return ((W + TWX - 1) / TWX) * ((H + ROWS - 1) / ROWS); }
+int vt_conv3x3_halo_fp8_tiles_shape(int H, int W, int shape) {
+    const int rows = shape == 1 ? Shape<4, 1>::ROWS : Shape<2, 1>::ROWS, twx = shape == 2 ? Shape<2, 2>::TWX : Shape<2, 1>::TWX;
+    return ((W + twx - 1) / twx) * ((H + rows - 1) / rows);
+}
+int vt_conv3x3_halo_fp8_tiles(int H, int W) { return vt_conv3x3_halo_fp8_tiles_shape(H, W, 0); }      // (the default shape has the most tiles)
 
 // LDS row (inside a 32-cout MFMA block) that must hold cout_local, so that accumulator register r of lane group g is cout 16 g + r
 int vt_halo_fp8_row_of_cout(int cout_local /*0..31*/) {
     const int gg = cout_local >> 4, q = (cout_local >> 2) & 3, t = cout_local & 3;
     return 8 * q + 4 * gg + t;
 }
+
+namespace {
+template <int WP, int WX>
+hipError_t launch_shape(const Conv3x3Fp8Args& a, hipStream_t s) {
+    typedef Shape<WP, WX> SH;
+    static std::atomic<unsigned long long> attr_done{0};
+    hipError_t ea = vt_once_per_device(attr_done, [&] { return hipFuncSetAttribute((const void*)conv3x3_halo_fp8_kernel<WP, WX>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::SMEM); });
+    if (ea != hipSuccess) return ea;
+    const long long tiles = (long long)((a.W + SH::TWX - 1) / SH::TWX) * ((a.H + SH::ROWS - 1) / SH::ROWS);
+    const long long nblk = tiles * (a.Cout / BC) * a.batch;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    Conv3x3Fp8Args k = a;
+    k.tiles_x = (a.W + SH::TWX - 1) / SH::TWX; k.ctiles = a.Cout / BC; k.per_img = (int)(tiles * k.ctiles); k.ptiles = (int)tiles;
+    auto magic = [&](long long d) -> unsigned long long {
+        return (nblk * d < (1LL << 40) && nblk < (1LL << 23)) ? ((1ULL << 40) / (unsigned long long)d + 1ULL) : 0ULL;
+    };
+    k.m_per_img = magic(k.per_img); k.m_ctiles = magic(k.ctiles); k.m_tiles_x = magic(k.tiles_x);
+    hipLaunchKernelGGL((conv3x3_halo_fp8_kernel<WP, WX>), dim3((unsigned)nblk), dim3(SH::NT), SH::SMEM, s, k);
+    return hipGetLastError();
+}
+}  // namespace
 
 hipError_t vt_launch_conv3x3_halo_fp8(const Conv3x3Fp8Args& a, hipStream_t s) {
     if (!a.X || !a.Wp || !a.mult || !a.zeros || (!a.out_f32 && !a.out_bf16 && !a.out_f16 && !a.out_e4m3)) return hipErrorInvalidValue;
@@ -552,18 +595,8 @@ hipError_t vt_launch_conv3x3_halo_fp8(const Conv3x3Fp8Args& a, hipStream_t s) {
     if ((long long)(a.Cin / 64) * 9 * a.Cout * 64 >= (1LL << 31)) return hipErrorInvalidValue;
     if ((a.scX != nullptr) != (a.scW != nullptr)) return hipErrorInvalidValue;
     if (a.scX && (a.scCin <= 0 || (a.scCin % 32) || a.res || a.res_f16 || (long long)a.H * a.W * a.scCin >= (1LL << 31))) return hipErrorInvalidValue;
-    static std::atomic<unsigned long long> attr_done{0};
-    hipError_t ea = vt_once_per_device(attr_done, [&] { return hipFuncSetAttribute((const void*)conv3x3_halo_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); });
-    if (ea != hipSuccess) return ea;
-    const long long tiles = vt_conv3x3_halo_fp8_tiles(a.H, a.W);
-    const long long nblk = tiles * (a.Cout / BC) * a.batch;
-    if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    Conv3x3Fp8Args k = a;
-    k.tiles_x = (a.W + TWX - 1) / TWX; k.ctiles = a.Cout / BC; k.per_img = (int)(tiles * k.ctiles); k.ptiles = (int)tiles;
-    auto magic = [&](long long d) -> unsigned long long {
-        return (nblk * d < (1LL << 40) && nblk < (1LL << 23)) ? ((1ULL << 40) / (unsigned long long)d + 1ULL) : 0ULL;
-    };
-    k.m_per_img = magic(k.per_img); k.m_ctiles = magic(k.ctiles); k.m_tiles_x = magic(k.tiles_x);
-    hipLaunchKernelGGL(conv3x3_halo_fp8_kernel, dim3((unsigned)nblk), dim3(NT), SMEM, s, k);
-    return hipGetLastError();
+    if (a.shape == 1) return launch_shape<4, 1>(a, s);
+    if (a.shape == 2) return launch_shape<2, 2>(a, s);
+    if (a.shape != 0) return hipErrorInvalidValue;
+    return launch_shape<2, 1>(a, s);
 }

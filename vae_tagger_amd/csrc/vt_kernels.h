@@ -58,8 +58,9 @@ constexpr int VT_PROF_ATTN_QK8 = 15;     // fp8 Q.K^T / P.V (attn_fp8.hip)
 constexpr int VT_PROF_ATTN_PV8 = 16;
 constexpr int VT_PROF_S2_HALO_FP8 = 17;  // stride-2 phase-plane conv on e4m3 operands (conv3x3_s2_halo_fp8.hip)
 constexpr int VT_PROF_PROJ_FP8 = 18;     // fp8 mode's q | k and v projections (attn_fp8.hip, proj_fp8_kernel)
-constexpr int VT_PROF_GN_APPLY = 19;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
-constexpr int VT_NUM_PROF_SLOTS = 20;
+constexpr int VT_PROF_HALO_FP8_C128 = 19; // the fp8 halo conv's launches with Cin <= 128 (18 K-steps per tile), same kernel name as slot 11: tools read them apart
+constexpr int VT_PROF_GN_APPLY = 20;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 21;
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
@@ -241,11 +242,13 @@ struct Conv3x3Fp8Args {
     // optional fused 1x1 conv (conv_shortcut) on bf16 operands: out += scW . scX; then no residual.  scX NHWC bf16
     // [batch][H][W][scCin]; scW [scCin/32][Cout rows in the fp8 kernel's permuted order][32] bf16, pre-divided by mult[cout]
     const bf16_t* scX; const bf16_t* scW; int scCin;
+    int shape;                                             // tile: 0 = 8 x 32 px on 4 waves (two workgroups per CU), 1 = 16 x 32 px, 2 = 8 x 64 px on 8 waves (one per CU)
     int tiles_x, ctiles, per_img, ptiles;                  // filled by the launcher
     unsigned long long m_per_img, m_ctiles, m_tiles_x;
 };
 bool vt_conv3x3_halo_fp8_supported(int Cin, int Cout);
-int vt_conv3x3_halo_fp8_tiles(int H, int W);              // GroupNorm partials per image its epilogue writes
+int vt_conv3x3_halo_fp8_tiles(int H, int W);              // GroupNorm partials per image its epilogue writes (default shape: the upper bound)
+int vt_conv3x3_halo_fp8_tiles_shape(int H, int W, int shape);
 int vt_halo_fp8_row_of_cout(int cout_local /*0..31*/);
 hipError_t vt_launch_conv3x3_halo_fp8(const Conv3x3Fp8Args& a, hipStream_t s);
 
