@@ -86,6 +86,10 @@ int vt_summarize_confidence(vt_context* ctx, const float* conf_sorted, const int
                             float* stats_out /* [B][4] */, void* stream);
 enum { VT_STATUS_NONFINITE = 1, VT_STATUS_FP8_SATURATED = 2 };
 int vt_status(vt_context* ctx, int clear, int* status_out /* host */, void* stream);
+/* the same word WITHOUT a host synchronisation: copied (and optionally cleared) in stream order into `status_out`, which is pinned host
+ * memory or device memory and is valid once work recorded on `stream` behind this call has completed (an event / a later sync).  The
+ * pipelined CLIs read batch n's word this way while batch n + 1 runs (infer_full.py:95-128 is the serial loop they replace). */
+int vt_status_async(vt_context* ctx, int clear, int* status_out /* pinned host or device */, void* stream);
 size_t vt_encode_tag_workspace_bytes(const vt_context* ctx, int B, int H, int W);
 int vt_encode_tag(vt_context* ctx, const float* x_nchw, int B, int H, int W, float* latent_out /* may be NULL */,
                   float* logits_out, void* workspace, size_t workspace_bytes, void* stream);

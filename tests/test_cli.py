@@ -19,8 +19,8 @@ def _flags(parser):
 
 def test_cli_flags_match_reference():
     assert REF_FULL_FLAGS <= _flags(infer_full.build_parser())
-    assert _flags(infer_full.build_parser()) - REF_FULL_FLAGS == {"--batch_size", "--device_resize", "--fp8"}
-    assert _flags(infer_vae.build_parser()) - REF_VAE_FLAGS == {"--batch_size"}
+    assert _flags(infer_full.build_parser()) - REF_FULL_FLAGS == {"--batch_size", "--device_resize", "--host_resize", "--workers", "--serial", "--fp8"}
+    assert _flags(infer_vae.build_parser()) - REF_VAE_FLAGS == {"--batch_size", "--host_resize", "--workers"}
     a = infer_full.build_parser().parse_args(["--vae_checkpoint", "v", "--decoder_checkpoint", "d", "--image_path", "i",
                                               "--tags_csv_path", "t"])
     assert (a.resolution, a.confidence_threshold, a.output_dir, a.use_attention, a.use_cross_attention) == \
@@ -67,12 +67,16 @@ def test_infer_full_and_infer_vae_end_to_end(tmp_path, monkeypatch):
                                 "--confidence_threshold", "0.5", "--batch_size", "2"])
     written = json.loads((out / "classification_results.json").read_text())
     assert written == res_full and len(written) == 3
-    # the same run with resize + normalise on the GPU: Pillow's arithmetic reproduced exactly -> the identical JSON
-    res_dev = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint",
-                               str(tmp_path / "dec.pth"), "--image_path", str(imgs), "--tags_csv_path",
-                               str(tmp_path / "tags.csv"), "--output_dir", str(tmp_path / "out_dev"), "--resolution", str(res),
-                               "--confidence_threshold", "0.5", "--batch_size", "2", "--device_resize"])
-    assert res_dev == res_full
+    # the default route resizes + normalises on the GPU (Pillow's arithmetic reproduced exactly) and is pipelined; the reference's own
+    # route (PIL transforms on the CPU: --host_resize) and its loop shape (--serial: one batch at a time) write the identical JSON,
+    # key order included
+    for extra in (["--host_resize"], ["--serial"], ["--host_resize", "--serial", "--workers", "1"], ["--device_resize", "--batch_size", "3"]):
+        res_alt = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint",
+                                   str(tmp_path / "dec.pth"), "--image_path", str(imgs), "--tags_csv_path",
+                                   str(tmp_path / "tags.csv"), "--output_dir", str(tmp_path / "out_alt"), "--resolution", str(res),
+                                   "--confidence_threshold", "0.5", "--batch_size", "2"] + extra)
+        assert res_alt == res_full, extra
+        assert json.dumps(res_alt, sort_keys=True) == json.dumps(written, sort_keys=True)
     # one image whose tensor holds a NaN (a decode that went wrong) in a batch of three: the device leg fails for the batch, is retried
     # image by image and loses exactly that ONE image, like the reference's per-image try/except (infer_full.py:130-132); the two
     # healthy images get the entries of the healthy run (batch composition does not change a bit), and fp16 storage stays on
@@ -91,11 +95,22 @@ def test_infer_full_and_infer_vae_end_to_end(tmp_path, monkeypatch):
     res_nan = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint",
                                str(tmp_path / "dec.pth"), "--image_path", str(imgs), "--tags_csv_path",
                                str(tmp_path / "tags.csv"), "--output_dir", str(tmp_path / "out_nan"), "--resolution", str(res),
-                               "--confidence_threshold", "0.5", "--batch_size", "4"])
-    monkeypatch.setattr(infer_full, "get_image_transform", real_tf)
+                               "--confidence_threshold", "0.5", "--batch_size", "4", "--host_resize"])
     bad = [k for k in res_full if k.endswith("img2.png")]
     assert len(bad) == 1 and set(res_nan) == set(res_full) - set(bad)
     assert all(res_nan[k] == res_full[k] for k in res_nan)
+    # the same poisoned image under --fp8: a NaN raises BOTH status bits (the e4m3 conversion clamps it and counts a clamp);
+    # that is bad input, not a checkpoint that saturates e4m3 -- fp8 mode stays on, nothing is redone in bf16, the healthy images get exactly
+    # the healthy fp8 run's entries
+    f8_args = ["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint", str(tmp_path / "dec.pth"), "--image_path", str(imgs),
+               "--tags_csv_path", str(tmp_path / "tags.csv"), "--resolution", str(res), "--confidence_threshold", "0.5", "--fp8", "--host_resize"]
+    nan_f8 = infer_full.main(f8_args + ["--output_dir", str(tmp_path / "out_nan8"), "--batch_size", "4"])
+    nan_f8_b1 = infer_full.main(f8_args + ["--output_dir", str(tmp_path / "out_nan8b"), "--batch_size", "1"])
+    monkeypatch.setattr(infer_full, "get_image_transform", real_tf)
+    healthy_f8 = infer_full.main(f8_args + ["--output_dir", str(tmp_path / "out_h8"), "--batch_size", "4"])
+    assert set(nan_f8) == set(res_full) - set(bad) == set(nan_f8_b1)
+    assert all(nan_f8[k] == healthy_f8[k] and nan_f8_b1[k] == healthy_f8[k] for k in nan_f8)
+    assert any(healthy_f8[k] != res_full[k] for k in nan_f8)                  # (fp8 entries do differ from bf16 ones: the mode really stayed on)
     # opt-in fp8 mode (BASELINE configs[4]): the same schema; confidences within 1e-2 of the default path's
     res_f8 = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--decoder_checkpoint",
                               str(tmp_path / "dec.pth"), "--image_path", str(imgs), "--tags_csv_path",
@@ -116,9 +131,37 @@ def test_infer_full_and_infer_vae_end_to_end(tmp_path, monkeypatch):
     big_bf16 = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae_big.safetensors"), "--output_dir", str(tmp_path / "out_b0")] + common)
     big_fp8 = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae_big.safetensors"), "--output_dir", str(tmp_path / "out_b8"), "--fp8"] + common)
     assert len(big_bf16) == 3 and big_fp8 == big_bf16
+    # saturation that first shows in a LATER batch (the redo of earlier fp8 entries was never run): the status word is forced
+    # on the second device batch -- the run must end with ONE numeric mode, i.e. exactly the bf16 run's file
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+    real_async, real_status, calls = EncodeTagPipeline.status_async, EncodeTagPipeline.status, {"n": 0, "armed": False}
+
+    def late_saturation(self, out, clear=True):
+        real_async(self, out, clear)
+        calls["n"] += 1
+        if calls["n"] == 2:
+            torch.cuda.current_stream(self.device).synchronize()
+            out[0] = 2                                                  # VT_STATUS_FP8_SATURATED reported for the second batch ...
+            calls["armed"] = True
+
+    def status_once(self, clear=True):
+        st = real_status(self, clear)
+        if calls["armed"]:
+            calls["armed"] = False
+            return st | 2                                               # ... and again when the synchronous leg reruns it in fp8 mode
+        return st
+    monkeypatch.setattr(EncodeTagPipeline, "status_async", late_saturation)
+    monkeypatch.setattr(EncodeTagPipeline, "status", status_once)
+    late = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--output_dir", str(tmp_path / "out_late"), "--fp8"] + common[:-1] + ["1"])
+    monkeypatch.setattr(EncodeTagPipeline, "status_async", real_async)
+    monkeypatch.setattr(EncodeTagPipeline, "status", real_status)
+    assert calls["n"] >= 2 and late == res_full
     lat = infer_vae.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--image_path", str(imgs),
                           "--output_dir", str(out), "--resolution", str(res)])
     assert len(lat) == 3 and all(len(v) == 16 * (res // 8) ** 2 for v in lat.values())
+    lat_host = infer_vae.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--image_path", str(imgs),
+                               "--output_dir", str(tmp_path / "out_lh"), "--resolution", str(res), "--host_resize", "--batch_size", "2"])
+    assert lat_host == lat
     # against the CPU oracle on the same preprocessed pixels
     tf = get_image_transform(res)
     sd_e.pop("decoder.conv_in.weight")
@@ -192,3 +235,43 @@ def test_cli_at_configs0_shape_single_512_image(tmp_path):
     # the written order is the sort order: confidences descending
     cs = [t["confidence"] for t in entry["predicted_tags"]]
     assert cs == sorted(cs, reverse=True)
+
+
+@pytest.mark.gpu
+def test_sharded_cli_two_ranks_rehearsal(tmp_path):
+    """`torchrun --nproc-per-node 2 -m vae_tagger_amd.infer_full / infer_vae`: the image list is split with sharding.shard_range, each rank runs its
+    share through the pipelined loop and rank 0 writes the merged file -- the same entries as the one-process run.  Both ranks share GPU 0 here
+    and the object gather runs on gloo (VT_CLI_GLOO=1; RCCL needs one GPU per rank); the process group is created before any GPU call."""
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    from safetensors.torch import save_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_tags, res = 40, 96
+    g = torch.Generator().manual_seed(7)
+    imgs = tmp_path / "imgs"
+    imgs.mkdir()
+    for i in range(7):
+        arr = (torch.rand(64 + 8 * i, 120 - 4 * i, 3, generator=g) * 255).to(torch.uint8).numpy()
+        Image.fromarray(arr).save(imgs / f"img{i}.{'jpg' if i % 2 else 'png'}")
+    (imgs / "broken.png").write_bytes(b"not a png")
+    save_file(synth.synth_state_dict(synth.encoder_manifest(), seed=0), str(tmp_path / "vae.safetensors"))
+    torch.save(synth.synth_state_dict(synth.attention_decoder_manifest(n_tags), seed=1), tmp_path / "dec.pth")
+    (tmp_path / "tags.csv").write_text("name\n" + "\n".join(f"tag_{i:05d}" for i in range(n_tags)) + "\n")
+    common = ["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--image_path", str(imgs), "--resolution", str(res), "--batch_size", "2"]
+    full = common + ["--decoder_checkpoint", str(tmp_path / "dec.pth"), "--tags_csv_path", str(tmp_path / "tags.csv")]
+    one = infer_full.main(full + ["--output_dir", str(tmp_path / "one")])
+    one_lat = infer_vae.main(common + ["--output_dir", str(tmp_path / "one")])
+    assert len(one) == 7 == len(one_lat)
+    env = dict(os.environ, VT_CLI_GLOO="1", PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    for mod, args, name, want in (("vae_tagger_amd.infer_full", full, "classification_results.json", one),
+                                  ("vae_tagger_amd.infer_vae", common, "latent_vectors.json", one_lat)):
+        port = str(29700 + os.getpid() % 200)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", port, "-m", mod] + args + ["--output_dir", str(tmp_path / "two")]
+        r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        got = json.loads((tmp_path / "two" / name).read_text())
+        assert got == want
+        assert "失败: 1" in r.stdout.decode()                         # the broken file is counted once, on the rank that owns it

@@ -273,3 +273,38 @@ def test_bench_socket_power_picks_the_loaded_card_and_tolerates_missing_files(tm
     with q:
         time.sleep(0.2)
     assert q.summary() is None
+
+
+_GATHER_WORKER = '''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK=sys.argv[3], WORLD_SIZE="2")
+dist.init_process_group("gloo")
+from vae_tagger_amd import infer_full, sharding
+rank = int(sys.argv[3])
+paths = [f"/data/img{i:02d}.png" for i in range(7)]
+lo, hi = sharding.shard_range(len(paths), rank, 2)
+items = [(p, {"max_confidence": float(i)}) for i, p in enumerate(paths)][lo:hi]
+if rank == 1:
+    items = items[:-1]                                   # rank 1 lost its last image
+merged, processed, errors = infer_full.gather_results(items, len(items), 1 if rank == 1 else 0, 2, rank)
+if rank == 0:
+    assert [p for p, _ in merged] == paths[:6] and processed == 6 and errors == 1, (merged, processed, errors)
+else:
+    assert merged is None and processed == 0 and errors == 0
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_cli_result_gather_world2_gloo(tmp_path):
+    """The sharded CLIs' only exchange: rank 0 receives every rank's finished entries and counters in rank (= path) order."""
+    script = tmp_path / "gather_worker.py"
+    script.write_text(_GATHER_WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

@@ -35,6 +35,7 @@ PROTOTYPES = {
     "vt_get_confidence": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "vt_summarize_confidence": (_i, [_vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "vt_status": (_i, [_vp, _i, _c.POINTER(_i), _vp]),
+    "vt_status_async": (_i, [_vp, _i, _vp, _vp]),
     "vt_encode_tag_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "vt_encode_tag": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vt_preprocess_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -1469,6 +1469,16 @@ int vt_status(vt_context* c, int clear, int* status_out, void* stream) {
     return VT_OK;
 }
 
+int vt_status_async(vt_context* c, int clear, int* status_out, void* stream) {
+    if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
+    if (!status_out) return c->fail(VT_ERR_INVALID, "vt_status_async: null output");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCK(c, hipMemcpyAsync(status_out, c->status, sizeof(int), hipMemcpyDefault, s), "vt_status_async copy");
+    if (clear) HIPCK(c, hipMemsetAsync(c->status, 0, sizeof(int), s), "vt_status_async clear");
+    return VT_OK;
+}
+
 size_t vt_encode_tag_workspace_bytes(const vt_context* c, int B, int H, int W) {
     if (!c || !c->enc.configured || !c->dec_configured || B <= 0 || H < 8 || W < 8) return 0;
     const EncPlan p = plan_encoder(c->enc, B, H, W);

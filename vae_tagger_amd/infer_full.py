@@ -6,7 +6,11 @@ same skip-and-count behaviour), running encode+tag on MI355X through libvae_tagg
 
 Differences from the reference, all outside the numbers it writes (`--fp8` is the exception: an opt-in faster mode whose logits
 stay within 1e-2 of the default path's):
-  * images are processed in same-shape batches (`--batch_size`, new flag; the reference runs one at a time);
+  * images are processed in same-shape batches (`--batch_size`, new flag; the reference runs one at a time), PIPELINED: a thread pool
+    decodes files ahead, a side stream uploads uint8 pixels and resizes / normalises them on the GPU (Pillow's arithmetic, bit for bit)
+    while the previous batch is in the encoder, and a batch's results are read after the next one has been enqueued (prefetch.py);
+    `--host_resize` is the reference's CPU transform route, `--serial` its one-at-a-time loop shape -- the JSON is the same either way;
+  * under `torchrun` (WORLD_SIZE > 1) the image list is sharded over the ranks (one GPU each) and rank 0 writes the merged file;
   * sigmoid + sort run on the device and come back in one copy per batch (the reference does 2*N .item() syncs
     per image, infer_full.py:109-111);
   * checkpoints are read with tensor-only loaders (safetensors / torch.load(weights_only=True)).
@@ -76,6 +80,7 @@ def load_models(args, device="cuda"):
     return vae_model, decoder, tags_df["name"].tolist()
 
 
+LAST_RUN_STATS = {}   # filled by infer_and_classify: seconds spent in the image loop of this rank and its image count (tools/bench_cli.py reads it)
 TOP_K = 64          # (confidence, tag) pairs fetched per image with the summary; images with more tags above the threshold fetch their prefix
 
 
@@ -94,12 +99,11 @@ def summarize(conf_row, idx_row, tag_names, threshold):
             "avg_confidence_top5": float(f"{sum(top5) / 5:.4f}")}      # always divides by 5, like the reference
 
 
-def summarize_batch(pipe, conf, idx, tag_names, threshold, top_k=TOP_K):
-    """conf / idx: sorted device tensors [B,N] (pipe.tag).  Threshold count, top-k, max and top-5 mean come from the
-    device (vt_summarize_confidence): formatting only on the host.  Raises FloatingPointError on non-finite confidences."""
-    top_conf, top_idx, stats = pipe.summarize(conf, idx, threshold, top_k)
+def _entries_from_summary(summary, conf, idx, tag_names):
+    """JSON entries from the host arrays of the device-side summary (formatting only).  Raises FloatingPointError on non-finite confidences."""
+    top_conf, top_idx, stats = summary
     out = []
-    for b in range(conf.shape[0]):
+    for b in range(stats.shape[0]):
         count, mx, avg5, bad = int(stats[b, 0]), float(stats[b, 1]), float(stats[b, 2]), int(stats[b, 3])
         if bad:
             raise FloatingPointError(f"{bad} non-finite confidences: activations left the fp16 range of the residual stream "
@@ -114,123 +118,260 @@ def summarize_batch(pipe, conf, idx, tag_names, threshold, top_k=TOP_K):
     return out
 
 
+def summarize_batch(pipe, conf, idx, tag_names, threshold, top_k=TOP_K):
+    """conf / idx: sorted device tensors [B,N] (pipe.tag).  Threshold count, top-k, max and top-5 mean come from the
+    device (vt_summarize_confidence): formatting only on the host.  Raises FloatingPointError on non-finite confidences."""
+    return _entries_from_summary(pipe.summarize(conf, idx, threshold, top_k), conf, idx, tag_names)
+
+
+def _dist_setup():
+    """(world, rank, device index).  Under torchrun (WORLD_SIZE > 1) the process group is created here, BEFORE any GPU call of this
+    process: "nccl" (= RCCL) with one GPU per rank, "gloo" when the ranks have to share GPUs (a rehearsal on a one-GPU box,
+    VT_CLI_GLOO=1).  The image list is split by `sharding.shard_range`; the only exchange is a gather of the finished entries."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 1, 0, None
+    import torch.distributed as dist
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    ngpu = torch.cuda.device_count()                       # (counting devices does not initialise the GPU)
+    if ngpu < 1:
+        raise RuntimeError("vae_tagger_amd needs an MI355X (no HIP device visible; there is no CPU fallback)")
+    gloo = os.environ.get("VT_CLI_GLOO") == "1" or ngpu < int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return world, rank, local % ngpu
+
+
+def gather_results(items, processed, errors, world, rank):
+    """Rank 0 receives every rank's [(path, entry)] and counters (torch.distributed.gather_object); the others get (None, 0, 0)."""
+    if world == 1:
+        return items, processed, errors
+    import torch.distributed as dist
+    objs = [None] * world if rank == 0 else None
+    dist.gather_object((items, processed, errors), objs, dst=0)
+    if rank != 0:
+        return None, 0, 0
+    merged = [it for part in objs for it in part[0]]
+    return merged, sum(part[1] for part in objs), sum(part[2] for part in objs)
+
+
+class _Tagger:
+    """The device leg of the loop: one batch -> JSON entries, with the health word's fall-backs (fp16 -> fp32 residual storage, fp8 -> bf16) and the
+    reference's error granularity (a failure costs ONE image: infer_full.py:130-132)."""
+
+    def __init__(self, pipe, tag_names, threshold, fp8):
+        self.pipe, self.tag_names, self.thr = pipe, tag_names, threshold
+        self.fp8 = bool(fp8)            # current numeric mode of the context
+        self.fp32_res = False
+        self.epoch = 0                  # bumped by every permanent mode switch: batches enqueued before it are redone
+        if self.fp8:
+            pipe.set_fp8(True)
+
+    def _run(self, x):
+        conf, idx = self.pipe.tag(x)
+        return conf, idx, self.pipe.status()
+
+    def tag_batch(self, x):
+        """Synchronous: one device batch -> (entries, fp8 mode they were computed in).  A raised health word is resolved here:
+          * bad INPUT (NaN / inf pixels) raises bit 0 whatever the storage -- and in fp8 mode bit 1 as well, because the e4m3 conversion
+            clamps a NaN to +-448 and counts it as a clamp: if the batch is still non-finite on the most conservative setting (bf16
+            operands, fp32 residual storage) it is the input, every setting is restored and the caller skips the image;
+          * otherwise the switch that cured it is permanent (a property of the checkpoint): fp32 residual storage for bit 0, and
+            bf16 operands if fp8 mode still clamps with it."""
+        pipe = self.pipe
+        conf, idx, st = self._run(x)
+        if st:
+            was_fp8, was_res = self.fp8, self.fp32_res
+            if st & VT_STATUS_NONFINITE or (st & VT_STATUS_FP8_SATURATED and not was_fp8):
+                pipe.set_fp8(False); pipe.set_fp32_residual(True)
+                conf, idx, st2 = self._run(x)
+                if st2 & VT_STATUS_NONFINITE:
+                    pipe.set_fp8(was_fp8); pipe.set_fp32_residual(was_res)          # not the checkpoint: one bad image must not change the run
+                    raise FloatingPointError("non-finite activations even with bf16 operands and fp32 residual storage (inf / NaN pixels or weights?)")
+                print("警告: 激活值超出fp16范围，改用fp32残差存储重新计算该批次")
+                self.fp32_res = True
+                self.epoch += 1
+                if was_fp8:
+                    pipe.set_fp8(True)
+                    c8, i8, st8 = self._run(x)
+                    if st8 == 0:
+                        conf, idx = c8, i8
+                    else:
+                        pipe.set_fp8(False)
+                        print("警告: 激活值超出fp8(e4m3)范围，改用bf16路径")
+                        self.fp8 = False
+            else:
+                # fp8 mode and this checkpoint's activations exceed the e4m3 range: the clamped values are not worth tags; bf16 from here on
+                print("警告: 激活值超出fp8(e4m3)范围，改用bf16路径重新计算该批次")
+                pipe.set_fp8(False)
+                self.fp8 = False
+                self.epoch += 1
+                conf, idx, st2 = self._run(x)
+                if st2 & VT_STATUS_NONFINITE:
+                    pipe.set_fp32_residual(True)
+                    conf, idx, st3 = self._run(x)
+                    if st3 & VT_STATUS_NONFINITE:
+                        pipe.set_fp32_residual(self.fp32_res)
+                        raise FloatingPointError("non-finite activations even with fp32 residual storage (inf / NaN pixels or weights?)")
+                    print("警告: 激活值超出fp16范围，改用fp32残差存储")
+                    self.fp32_res = True
+        return summarize_batch(pipe, conf, idx, self.tag_names, self.thr), self.fp8
+
+    def clear_status(self):
+        try:
+            self.pipe.status(clear=True)                 # the sticky word must not leak into the next healthy batch
+        except Exception:  # noqa: BLE001
+            pass
+
+    def device_leg(self, x, names):
+        """Tag one batch synchronously; when the batch fails, retry it image by image so that an error costs ONE image, as in the
+        reference's per-image loop (infer_full.py:130-132).  Returns [(path, entry, fp8 mode of the entry)] and the number of images lost."""
+        try:
+            entries, f8 = self.tag_batch(x)
+            return [(p, e, f8) for p, e in zip(names, entries)], 0
+        except Exception as e:  # noqa: BLE001
+            self.clear_status()
+            if len(names) == 1:
+                print(f"跳过图像 {names[0]}，错误原因: {e}")
+                return [], 1
+        done, lost = [], 0
+        for k, p in enumerate(names):
+            try:
+                entries, f8 = self.tag_batch(x[k:k + 1])
+                done.append((p, entries[0], f8))
+            except Exception as e:  # noqa: BLE001 - skip-and-count (infer_full.py:130-132)
+                self.clear_status()
+                lost += 1
+                print(f"跳过图像 {p}，错误原因: {e}")
+        return done, lost
+
+    # ---- pipelined form: enqueue batch n, read its word and summary while batch n + 1 runs ----
+    def enqueue(self, x, names):
+        pipe = self.pipe
+        rec = {"x": x, "names": names, "epoch": self.epoch, "fp8": self.fp8, "ok": False}
+        try:
+            conf, idx = pipe.tag(x)
+            host, K = pipe.summarize_async(conf, idx, self.thr, TOP_K)
+            word = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            pipe.status_async(word)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(pipe.device))
+            rec.update(conf=conf, idx=idx, host=host, K=K, word=word, ev=ev, ok=True)
+        except Exception as e:  # noqa: BLE001 - resolved by the synchronous leg in finish()
+            rec["error"] = e
+        return rec
+
+    def finish(self, rec):
+        """-> ([(path, entry, fp8 mode)], images lost).  The fast path only formats; anything unusual -- a raised word, a failed call, non-finite
+        confidences, a mode switch since the batch was enqueued -- goes through the synchronous leg on the same device tensor."""
+        if rec["ok"]:
+            rec["ev"].synchronize()
+            if rec["epoch"] == self.epoch and int(rec["word"][0]) == 0:
+                try:
+                    entries = _entries_from_summary(self.pipe.unpack_summary(rec["host"], rec["K"]), rec["conf"], rec["idx"], self.tag_names)
+                    return [(p, e, rec["fp8"]) for p, e in zip(rec["names"], entries)], 0
+                except Exception:  # noqa: BLE001
+                    pass
+        return self.device_leg(rec["x"], rec["names"])
+
+
 def infer_and_classify(args):
+    world, rank, dev_index = _dist_setup()
     if not torch.cuda.is_available():
         raise RuntimeError("vae_tagger_amd needs an MI355X (no HIP device visible; there is no CPU fallback)")
-    device = "cuda"
+    device = "cuda" if dev_index is None else f"cuda:{dev_index}"
+    if dev_index is not None:
+        torch.cuda.set_device(dev_index)
     print(f"Using device: {device}")
     vae_model, decoder, tag_names = load_models(args, device)
     transform = get_image_transform(args.resolution)
     if not os.path.exists(args.image_path):
         raise FileNotFoundError(f"图像路径未找到: {args.image_path}")
     image_paths = get_image_paths(args.image_path)
+    if world > 1:
+        import torch.distributed as dist
+        box = [image_paths]                              # the reference's order is a set's: every rank works from rank 0's list
+        dist.broadcast_object_list(box, src=0)
+        image_paths = box[0]
     if not image_paths:
         print("未找到任何图像文件，请检查路径。")
         return
+    from . import sharding
+    from .prefetch import BatchFeeder
+    lo, hi = sharding.shard_range(len(image_paths), rank, world)
+    my_paths = image_paths[lo:hi]
     pipe = EncodeTagPipeline(vae_model, decoder)
-    if getattr(args, "fp8", False):
-        pipe.set_fp8(True)
-    from PIL import Image
-    results, processed, errors = {}, 0, 0
+    tg = _Tagger(pipe, tag_names, args.confidence_threshold, getattr(args, "fp8", False))
     bs = max(1, int(getattr(args, "batch_size", 8)))
+    host_resize = bool(getattr(args, "host_resize", False))
+    serial = bool(getattr(args, "serial", False))
+    results, entry_fp8 = {}, {}
+    counts = {"processed": 0, "errors": 0}
+    main = torch.cuda.current_stream(pipe.device)
 
-    def load(p):
-        img = Image.open(p).convert("RGB")
-        return pipe.load_image(img, resolution=args.resolution) if getattr(args, "device_resize", False) else transform(img)
-
-    def tag_batch(x):
-        """One device batch -> JSON entries.  Both status bits are re-read after every run; a mode switch is permanent."""
-        conf, idx = pipe.tag(x)
-        st = pipe.status()
-        if st & VT_STATUS_FP8_SATURATED:
-            # --fp8 and this checkpoint's activations exceed the e4m3 range: the clamped values are not worth tags; bf16 from here on
-            print("警告: 激活值超出fp8(e4m3)范围，改用bf16路径重新计算该批次")
-            pipe.set_fp8(False)
-            state["fp8"] = False
-            conf, idx = pipe.tag(x)
-            st = pipe.status()
-        if st & VT_STATUS_NONFINITE:
-            # an activation left the fp16 range of the residual-stream storage: keep fp32 storage from here on
-            print("警告: 激活值超出fp16范围，改用fp32残差存储重新计算该批次")
-            pipe.set_fp32_residual(True)
-            conf, idx = pipe.tag(x)
-            st = pipe.status()
-            if st & VT_STATUS_FP8_SATURATED:            # (fp8 still on and only the fp32-storage run clamps)
-                pipe.set_fp8(False)
-                state["fp8"] = False
-                conf, idx = pipe.tag(x)
-                st = pipe.status()
-            if st & VT_STATUS_NONFINITE:
-                pipe.set_fp32_residual(False)           # storage was not the cause: one bad image must not slow the rest of the run
-                raise FloatingPointError("non-finite activations even with fp32 residual storage (inf / NaN pixels or weights?)")
-        return summarize_batch(pipe, conf, idx, tag_names, args.confidence_threshold)
-
-    def clear_status():
-        try:
-            pipe.status(clear=True)                      # the sticky word must not leak into the next healthy batch
-        except Exception:  # noqa: BLE001
-            pass
-
-    def device_leg(tensors, names):
-        """Tag one batch; when the batch fails, retry it image by image so that an error costs ONE image, as in the reference's
-        per-image loop (infer_full.py:130-132).  Returns [(path, entry)] and the number of images lost."""
-        try:
-            return list(zip(names, tag_batch(torch.stack(tensors).to(device)))), 0
-        except Exception as e:  # noqa: BLE001
-            clear_status()
-            if len(names) == 1:
-                print(f"跳过图像 {names[0]}，错误原因: {e}")
-                return [], 1
-        done, lost = [], 0
-        for t, p in zip(tensors, names):
-            try:
-                done.append((p, tag_batch(t[None].to(device))[0]))
-            except Exception as e:  # noqa: BLE001 - skip-and-count (infer_full.py:130-132)
-                clear_status()
-                lost += 1
-                print(f"跳过图像 {p}，错误原因: {e}")
-        return done, lost
-
-    state = {"fp8": bool(getattr(args, "fp8", False))}
-    fp8_done = []                                        # paths whose entries were computed in fp8 mode
-    for start in range(0, len(image_paths), bs):
-        batch, names = [], []
-        for p in image_paths[start:start + bs]:
-            try:
-                batch.append(load(p))
-                names.append(p)
-            except Exception as e:  # noqa: BLE001 - skip-and-count (infer_full.py:130-132)
-                errors += 1
-                print(f"跳过图像 {p}，错误原因: {e}")
-        if not batch:
-            continue
-        was_fp8 = state["fp8"]
-        done, lost = device_leg(batch, names)
-        errors += lost
-        for p, entry in done:
+    def take(done, lost):
+        counts["errors"] += lost
+        for p, entry, f8 in done:
+            if str(p) not in results:
+                counts["processed"] += 1
             results[str(p)] = entry
-            processed += 1
-        if was_fp8 and state["fp8"]:
-            fp8_done.extend(p for p, _ in done)
-        elif was_fp8 and fp8_done:
-            # fp8 was abandoned in this batch: ONE output file holds ONE numeric mode -- the earlier fp8 batches are redone in bf16
-            print(f"重新以bf16计算之前的 {len(fp8_done)} 张图像")
-            for s0 in range(0, len(fp8_done), bs):
-                redo = fp8_done[s0:s0 + bs]
-                try:
-                    again, lost = device_leg([load(p) for p in redo], redo)
-                except Exception as e:  # noqa: BLE001
-                    again, lost = [], len(redo)
-                    print(f"跳过图像 {[str(n) for n in redo]}，错误原因: {e}")
-                for p in redo:
-                    results.pop(str(p), None)
-                for p, entry in again:
-                    results[str(p)] = entry
-                processed -= lost
-                errors += lost
-            fp8_done = []
-        if (start // bs + 1) % max(1, 100 // bs) == 0:
-            print(f"已处理 {processed}/{len(image_paths)} 图像 (跳过 {errors} 个错误)")
+            entry_fp8[str(p)] = f8
+
+    def run(paths, progress=True):
+        """paths -> entries, pipelined: the decode pool and the side stream build batch n + 1 while batch n is in the encoder, and batch n's
+        health word + summary are read after batch n + 1 has been enqueued (`--serial`: one batch at a time, as the reference's loop)."""
+        from collections import deque
+        inflight, seen = deque(), 0
+        feeder = BatchFeeder(pipe, paths, bs, args.resolution, workers=getattr(args, "workers", None) or None,
+                             host_resize=host_resize, transform=transform)
+        for names, x, ready, failed in feeder:
+            for p, e in failed:
+                counts["errors"] += 1
+                print(f"跳过图像 {p}，错误原因: {e}")
+            if names:
+                main.wait_event(ready)
+                x.record_stream(main)
+                inflight.append(tg.enqueue(x, names))
+            while len(inflight) > (0 if serial else 1):
+                take(*tg.finish(inflight.popleft()))
+            seen += len(names) + len(failed)
+            if progress and (seen // bs) % max(1, 100 // bs) == 0:
+                print(f"已处理 {counts['processed']}/{len(paths)} 图像 (跳过 {counts['errors']} 个错误)")
+        while inflight:
+            take(*tg.finish(inflight.popleft()))
+
+    import time
+    t_loop = time.perf_counter()
+    run(my_paths)
+    torch.cuda.synchronize()
+    LAST_RUN_STATS.update(loop_seconds=time.perf_counter() - t_loop, images=len(my_paths), rank=rank, world=world)
+    # ONE output file holds ONE numeric mode: if fp8 was abandoned anywhere (on any rank), the entries computed in fp8 mode are redone in bf16
+    fp8_asked = bool(getattr(args, "fp8", False))
+    abandoned = fp8_asked and not tg.fp8
+    if world > 1 and fp8_asked:
+        import torch.distributed as dist
+        flag = torch.tensor([1 if abandoned else 0], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        abandoned = bool(int(flag.item()))
+        if abandoned and tg.fp8:
+            pipe.set_fp8(False); tg.fp8 = False; tg.epoch += 1
+    if abandoned:
+        redo = [p for p in my_paths if entry_fp8.get(str(p))]
+        if redo:
+            print(f"重新以bf16计算之前的 {len(redo)} 张图像")
+            for p in redo:
+                results.pop(str(p), None)
+            counts["processed"] -= len(redo)             # take() counts them again as they come back; images lost in the redo count as errors
+            run(redo, progress=False)
+    items = [(str(p), results[str(p)]) for p in my_paths if str(p) in results]
+    items, processed, errors = gather_results(items, counts["processed"], counts["errors"], world, rank)
+    if rank != 0:
+        return None
+    results = dict(items)
     print(f"处理完成！成功: {processed}, 失败: {errors}, 总计: {len(image_paths)}")
     out = Path(args.output_dir) / "classification_results.json"
     out.parent.mkdir(parents=True, exist_ok=True)
@@ -260,7 +401,13 @@ def build_parser():
     p.add_argument("--model_checkpoint", type=str, default=None, help="(已弃用) 包含VAE和Decoder权重的父目录")
     p.add_argument("--batch_size", type=int, default=8, help="images per device batch (not in the reference)")
     p.add_argument("--device_resize", action="store_true",
-                   help="resize + normalise on the GPU (bit-exact with the PIL transform; not in the reference)")
+                   help="resize + normalise on the GPU (bit-exact with the PIL transform; not in the reference).  This is the default since the "
+                        "pipelined loader: the flag is accepted and changes nothing")
+    p.add_argument("--host_resize", action="store_true",
+                   help="the reference's own route: PIL Resize + ToTensor + Normalize on the CPU, fp32 tensors over PCIe (same JSON, slower)")
+    p.add_argument("--workers", type=int, default=0, help="image decode threads (0 = min(16, cores); not in the reference)")
+    p.add_argument("--serial", action="store_true",
+                   help="one batch at a time: wait for batch n's results before batch n + 1 is enqueued (the reference's loop shape; same JSON)")
     p.add_argument("--fp8", action="store_true",
                    help="3x3 convs of the encoder on fp8 (e4m3) operands / the fp8 MFMA: ~1.35x faster, logits within 1e-2 of the "
                         "bf16 path's reference, latents only to ~1e-1 (tagging only; not in the reference)")

@@ -63,10 +63,10 @@ class EncodeTagPipeline:
         return conf, idx
 
     @torch.no_grad()
-    def summarize(self, conf, idx, threshold, top_k=64):
-        """Device-side counterpart of the per-image loop of infer_full.py:106-125 on sorted (conf, idx): returns host arrays
-        (top_conf [B,K] fp32, top_idx [B,K] int32, stats [B,4] = count >= threshold, max, top-5 sum / 5, non-finite count)
-        from ONE small copy -- B x (2K + 4) values instead of the B x N x 12 bytes of the full sorted arrays."""
+    def summarize_async(self, conf, idx, threshold, top_k=64):
+        """Device-side counterpart of the per-image loop of infer_full.py:106-125 on sorted (conf, idx), WITHOUT a host synchronisation:
+        launches vt_summarize_confidence and an asynchronous copy of its B x (2K + 4) values into pinned host memory on the current stream.
+        Returns (packed pinned tensor, K); `unpack_summary` reads it once the stream has passed this point (an event / a sync)."""
         B, N = conf.shape
         K = int(max(5, min(top_k, N)))
         tc = torch.empty(B, K, dtype=torch.float32, device=conf.device)
@@ -74,8 +74,23 @@ class EncodeTagPipeline:
         st = torch.empty(B, 4, dtype=torch.float32, device=conf.device)
         self.ctx.call("vt_summarize_confidence", vp(conf), vp(idx), B, N, float(threshold), K, vp(tc), vp(ti), vp(st),
                       stream_ptr(conf.device))
-        packed = torch.cat([tc, ti.view(torch.float32), st], dim=1).cpu()           # one D2H copy
-        return (packed[:, :K].numpy(), packed[:, K:2 * K].contiguous().view(torch.int32).numpy(), packed[:, 2 * K:].numpy())
+        packed = torch.cat([tc, ti.view(torch.float32), st], dim=1)
+        host = torch.empty(packed.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(packed, non_blocking=True)                                         # one D2H copy
+        return host, K
+
+    @staticmethod
+    def unpack_summary(host, K):
+        """(top_conf [B,K] fp32, top_idx [B,K] int32, stats [B,4] = count >= threshold, max, top-5 sum / 5, non-finite count) as host arrays."""
+        return (host[:, :K].numpy(), host[:, K:2 * K].contiguous().view(torch.int32).numpy(), host[:, 2 * K:].numpy())
+
+    @torch.no_grad()
+    def summarize(self, conf, idx, threshold, top_k=64):
+        """`summarize_async` + wait: host arrays from ONE small copy -- B x (2K + 4) values instead of the B x N x 12 bytes of the full
+        sorted arrays."""
+        host, K = self.summarize_async(conf, idx, threshold, top_k)
+        torch.cuda.current_stream(conf.device).synchronize()
+        return self.unpack_summary(host, K)
 
     def status(self, clear=True):
         """Sticky health word of the context (synchronises): bit 0 = non-finite GroupNorm statistics were seen, i.e. an
@@ -125,6 +140,32 @@ class EncodeTagPipeline:
         self.ctx.call("vt_resize_u8", vp(t), H, W, left, top, cw, ch, vp(out), out_h, out_w, filt, ctypes.c_void_p(ptr), need,
                       stream_ptr(self.device))
         return out
+
+    @torch.no_grad()
+    def resize_u8_into(self, src, out, filt, box=None, tag="resize"):
+        """`resize_u8` for a uint8 [H,W,3] DEVICE tensor `src` into the caller's contiguous uint8 [out_h,out_w,3] device view `out`
+        (one slot of a batch buffer), on the current stream; `tag` names the scratch buffer (one per stream that resizes)."""
+        if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[-1] != 3 or not src.is_contiguous() or src.device != self.device:
+            raise ValueError(f"expected a contiguous uint8 [H,W,3] tensor on {self.device}, got {src.dtype} {tuple(src.shape)} on {src.device}")
+        if out.dtype != torch.uint8 or out.dim() != 3 or out.shape[-1] != 3 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("output must be a contiguous uint8 [h,w,3] view on the same device")
+        H, W, _ = src.shape
+        out_h, out_w, _ = out.shape
+        left, top, cw, ch = box if box is not None else (0, 0, W, H)
+        need = self.ctx.lib.vt_resize_workspace_bytes(ch, cw, out_h, out_w, filt)
+        if need == 0:
+            raise _lib.VTError(f"unsupported resize {cw}x{ch} -> {out_w}x{out_h}")
+        ws, ptr = workspace(self.device, need, tag)
+        self.ctx.call("vt_resize_u8", vp(src), H, W, left, top, cw, ch, vp(out), out_h, out_w, filt, ctypes.c_void_p(ptr), need,
+                      stream_ptr(self.device))
+        return out
+
+    def status_async(self, out, clear=True):
+        """The context's health word copied (and cleared) in stream order into `out` (int32 [1], pinned host or device) without a host
+        synchronisation (vt_status_async): valid once the current stream has passed this point."""
+        if out.dtype != torch.int32 or out.numel() < 1:
+            raise ValueError("status_async: int32 tensor expected")
+        self.ctx.call("vt_status_async", int(clear), ctypes.c_void_p(out.data_ptr()), stream_ptr(self.device))
 
     def load_image(self, img, resolution=None, bucket=None):
         """Device counterpart of `get_image_transform(resolution, bucket is not None, bucket)(img)`: a PIL image (or a
