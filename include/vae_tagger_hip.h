@@ -162,6 +162,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         per CU; 1 = 16 x 32 px, 2 = 8 x 64 px, both on 8 waves, one workgroup per CU (a staged weight tile serves twice the pixels);
  *         applied to the layers with Cin <= 128, or to every layer with value & 4.  The conv outputs are bit-identical for every value (the
  *         GroupNorm partials are per tile, so their merge order -- the last bits of the statistics -- follows the shape).
+ * flag 17: 1 (default) = the attention's bf16 q | k and v^T projections run on attn_qk.hip's skeleton (mode 4: one operand's rows in
+ *         registers, the other's streamed through LDS, bias + bf16 store in the epilogue); 0 = the generic GEMM (conv_gemm.hip).
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

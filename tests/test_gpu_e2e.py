@@ -523,10 +523,21 @@ def test_mid_attention_without_softmax_pass(gain, S):
                 assert (out - ref).abs().max().item() <= 2e-2       # bf16 P and o: ~4e-3 relative on |o| <= max|v|
             assert (outs[0] - outs[1]).abs().max().item() <= 1e-2
             assert torch.equal(outs[0], outs[1]) == (gain > 1)      # flagged <=> the exact-maximum path ran
+            if qk and pv:
+                # the q | k and v^T projections on attn_qk.hip's skeleton (flag 17, default) against the generic GEMM: the same bf16 products
+                # summed in another order -- both on the reference, and within bf16 rounding of each other
+                ctx.call("vt_set_flag", 7, 0)
+                ctx.call("vt_set_flag", 17, 0)
+                out = torch.full((B, S, C), float("nan"), device="cuda")
+                ctx.call("vt_op_attention", vp(xd), vp(rd), vp(out), B, S, C, vp(ws), ctypes.c_void_p(0))
+                torch.cuda.synchronize()
+                ctx.call("vt_set_flag", 17, 1)
+                assert (out.cpu() - ref).abs().max().item() <= 2e-2 and (out.cpu() - outs[0]).abs().max().item() <= 1e-2
     finally:
         ctx.call("vt_set_flag", 7, 0)
         ctx.call("vt_set_flag", 9, 1)
         ctx.call("vt_set_flag", 12, 1)
+        ctx.call("vt_set_flag", 17, 1)
 
 
 @pytest.mark.parametrize("gain,S", [(1.0, 200), (6.0, 200), (1.0, 1024), (3.0, 1024), (1.0, 333), (1.0, 64), (1.0, 2048), (3.0, 2500), (1.0, 130)])

@@ -12,6 +12,9 @@
 //     beside the other resident wave's MFMAs.
 // mode 2: P[row][key] = exp(alpha * q.k - shift[row]) as bf16 (keys >= S: 0, up to ldp), rowval[row] = 1 / sum.
 // mode 1: no P; rowval[row] = max_key alpha * q.k (the exact shift of run_attention's flagged path).
+// mode 4 (round 4): the same skeleton as a linear layer of K = 512 (the attention's q | k and v^T projections): rows of one operand in
+//         registers, the other operand's rows streamed as "keys", out = bf16(alpha * q.k + kbias[key] + qbias[row]) row-major.  The generic
+//         GEMM ran these two launches at 0.5 PF (K = 512 is 8 of its K-steps: a tile lives in its prologue and epilogue).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -42,7 +45,9 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     const int b = logical / per_img, qs = logical - b * per_img;
     const int qt = qs / nsplit, ksp = qs - qt * nsplit;           // the splits of a query block are neighbours: they share its Q rows in L2
     const bf16_t* qb = a.q + (long long)b * a.qk_bs;
-    const bf16_t* kb = a.k + (long long)b * a.qk_bs;
+    const bf16_t* kb = a.k + (long long)b * (MODE == 4 ? a.k_bs : a.qk_bs);
+    const int nkeys = MODE == 4 ? a.nk : a.S;                     // rows of the streamed operand
+    const int ldk = MODE == 4 ? a.ldk : a.ldq;
     const int row0 = qt * QB + wave * 32;
 
     // ---- this wave's Q slab: B operand of k-step ks for row tile j = q[row0 + 16 j + fr][32 ks + 8 fq .. +8]
@@ -61,7 +66,8 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     for (int j = 0; j < 2; ++j) {
         const int row = row0 + j * 16 + fr;
         rv[j] = MODE == 1 ? -__builtin_inff() : 0.f;
-        sh2[j] = (MODE >= 2 && row < a.S) ? a.rowin[(long long)b * a.row_bs + row] * 1.44269504f : 0.f;
+        if (MODE == 4) sh2[j] = (a.qbias && row < a.S) ? a.qbias[row] : 0.f;          // (mode 4: the row's bias)
+        else sh2[j] = (MODE >= 2 && row < a.S) ? a.rowin[(long long)b * a.row_bs + row] * 1.44269504f : 0.f;
     }
     const float alpha2 = a.alpha * 1.44269504f;
 
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
         for (int jj = 0; jj < 8; ++jj) {
             const int R = wave * 8 + jj;
             const int key = kt * KT + 32 * ((R >> 5) & 1) + 8 * ((R >> 2) & 3) + 4 * ((R >> 4) & 1) + (R & 3);
-            const void* src = key < a.S ? (const void*)(kb + (long long)key * a.ldq + ((lane ^ (R & 15)) << 3)) : a.zeros;
+            const void* src = key < nkeys ? (const void*)(kb + (long long)key * ldk + ((lane ^ (R & 15)) << 3)) : a.zeros;
             __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(smem + buf * KBUF + R * KROWB), 16, 0, 0);
         }
     };
@@ -114,7 +120,19 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
             return;
         }
         const int key0 = kt_prev * KT + 8 * sp;                // half h: keys key0 + 32 h .. + 7
-        const bool full = kt_prev * KT + KT <= a.S;
+        const bool full = kt_prev * KT + KT <= nkeys;
+        if constexpr (MODE == 4) {                             // plain stores: the consumer (row norms / Q.K^T / P.V) reads the tensor next
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = row0 + j * 16 + sr;
+                if (row < a.S) {
+                    bf16_t* dst = a.P + (long long)b * a.p_bs + (long long)row * a.ldp + key0;
+                    if (full || key0 < a.ldp) *(bf16x8*)dst = hold[j][0];
+                    if (full || key0 + 32 < a.ldp) *(bf16x8*)(dst + 32) = hold[j][1];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = row0 + j * 16 + sr;
@@ -136,9 +154,13 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool real = FULL || key0 + 32 * (i >> 1) + 4 * (i & 1) + r < a.S;
+                    const bool real = FULL || key0 + 32 * (i >> 1) + 4 * (i & 1) + r < nkeys;
                     if (MODE == 1) {
                         if (real) rv[j] = fmaxf(rv[j], acc[i][j][r] * a.alpha);
+                    } else if (MODE == 4) {
+                        const int kk = key0 + 32 * (i >> 1) + 4 * (i & 1) + r;
+                        const float kbv = (a.kbias && real) ? a.kbias[kk] : 0.f;
+                        hold[j][i >> 1][(i & 1) * 4 + r] = (bf16_t)(real ? fmaf(acc[i][j][r], a.alpha, kbv + sh2[j]) : 0.f);
                     } else {
                         float e = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], alpha2, -sh2[j]));
                         if (!real) e = 0.f;
@@ -147,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
                     }
                 }
         }
-        if (MODE == 2) {  /* row-major P: lane permute */
+        if (MODE == 2 || MODE == 4) {  /* row-major P: lane permute */
             typedef int i32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -164,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     // reduced over the row's four lanes and written when its last tile's epilogue has run; attn_pv adds them in the fixed order
     // ((s0 + s1) + s2) + s3 and inverts.  The association of the additions is then the same whether one workgroup sweeps all keys or
     // (small grids) 2 or 4 workgroups share a query block's sweep: an image's result does not depend on the batch it ran in, bit for bit.
-    const int nkt_all = (a.S + KT - 1) / KT;
+    const int nkt_all = (nkeys + KT - 1) / KT;
     const int segb[5] = {0, nkt_all / 4, nkt_all / 2, (int)(3LL * nkt_all / 4), nkt_all};
     auto write_segment = [&](int seg, bool zero) __attribute__((always_inline)) {
 #pragma unroll
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
         }
     };
     auto epilogue = [&](int kt) __attribute__((always_inline)) {
-        if (kt * KT + KT <= a.S) epilogue_t(kt, std::true_type{});
+        if (kt * KT + KT <= nkeys) epilogue_t(kt, std::true_type{});
         else epilogue_t(kt, std::false_type{});
         if (MODE == 3) {
 #pragma unroll
@@ -196,7 +218,9 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     // and leaves the stores -- HBM writes -- a second interval to drain (vmcnt(0) parked the wave on them every tile).
     const bool late = (wave & 4) != 0;
     const int seg0 = ksp * (4 / nsplit), seg1 = (ksp + 1) * (4 / nsplit);      // nsplit = 1, 2 or 4: whole segments per workgroup
-    const int kt0 = MODE == 3 ? segb[seg0] : 0, nkt = MODE == 3 ? segb[seg1] : nkt_all;          // this workgroup's key tiles [kt0, nkt)
+    // this workgroup's key tiles [kt0, nkt): whole segments in the fragment-order mode, an even share of the tiles in the linear mode
+    const int kt0 = MODE == 3 ? segb[seg0] : MODE == 4 ? (int)((long long)ksp * nkt_all / nsplit) : 0;
+    const int nkt = MODE == 3 ? segb[seg1] : MODE == 4 ? (int)((long long)(ksp + 1) * nkt_all / nsplit) : nkt_all;
     const bool counted = MODE == 3 && row0 < a.S;              // this wave issues exactly 4 stores per epilogue
     stage(kt0, kt0 & 1);
     for (int kt = kt0; kt < nkt; ++kt) {
@@ -240,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
         epilogue(nkt - 1);
         if (MODE >= 2) store_held(nkt - 1);
     }
+    if constexpr (MODE == 4) return;
     if (MODE == 3) {
         // empty segments (fewer than four key tiles) still have a defined sum
 #pragma unroll
@@ -265,6 +290,20 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
 bool vt_attn_qk_supported(int S, int C) { return C == D && S > 0; }
 
 hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s) {
+    if (a.mode == 4) {
+        if (!a.q || !a.k || !a.P || !a.zeros || a.batch <= 0 || !vt_attn_qk_supported(a.S, a.C) || a.nk <= 0 || a.gate) return hipErrorInvalidValue;
+        if ((a.ldq % 8) || (a.ldk % 8) || (a.qk_bs % 8) || (a.k_bs % 8) || (a.ldp % 8) || (a.p_bs % 8) || a.ldp < (a.nk + 7) / 8 * 8) return hipErrorInvalidValue;
+        if ((long long)a.S * a.ldq >= (1LL << 31) || (long long)a.nk * a.ldk >= (1LL << 31)) return hipErrorInvalidValue;
+        const int nsp = a.nsplit > 1 ? a.nsplit : 1;
+        if (nsp > (a.nk + KT - 1) / KT) return hipErrorInvalidValue;
+        const long long nblk4 = (long long)((a.S + QB - 1) / QB) * a.batch * nsp;
+        if (nblk4 > 0x7fffffffLL) return hipErrorInvalidValue;
+        static std::atomic<unsigned long long> attr4{0};
+        hipError_t e4 = vt_once_per_device(attr4, [&] { return hipFuncSetAttribute((const void*)attn_qk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF); });
+        if (e4 != hipSuccess) return e4;
+        hipLaunchKernelGGL(attn_qk_kernel<4>, dim3((unsigned)nblk4), dim3(512), 2 * KBUF, s, a);
+        return hipGetLastError();
+    }
     if (!a.q || !a.k || !a.rowout || !a.zeros || a.batch <= 0 || !vt_attn_qk_supported(a.S, a.C)) return hipErrorInvalidValue;
     if (a.mode != 1 && a.mode != 2) return hipErrorInvalidValue;
     if (a.mode == 2 && (!a.P || !a.rowin || (a.p_bs % 8))) return hipErrorInvalidValue;

@@ -151,6 +151,7 @@ struct vt_context {
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
     int proj_fp8 = 1;               // vt_set_flag(ctx, 15, v): with the fp8 attention, the q | k and v projections on e4m3 operands too, writing q8 | k8 and v8^T directly
     int attn_fp8 = 1;               // vt_set_flag(ctx, 14, v): in fp8 mode (flag 11) Q.K^T and P.V run on e4m3 operands too (attn_fp8.hip)
+    int attn_proj_kernel = 1;       // vt_set_flag(ctx, 17, v): the bf16 q | k and v^T projections on attn_qk.hip's skeleton (mode 4) instead of the generic GEMM
     int fp8_tile = 0;               // vt_set_flag(ctx, 16, v): fp8 halo conv tile shape = v & 3 (0: 8 x 32 px, 4 waves, two workgroups per CU; 1: 16 x 32 px;
                                     // 2: 8 x 64 px, 8 waves, one per CU) on the layers with Cin <= 128, or on every layer with v & 4
     int s2_halo = 1;                // vt_set_flag(ctx, 13, v): stride-2 convs on the phase-plane halo kernel instead of the generic GEMM
@@ -741,6 +742,37 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
         } else {
             HIPCK(c, vt_launch_proj_fp8(pq, s), "attn qk proj fp8");
             HIPCK(c, vt_launch_proj_fp8(pv, s), "attn v proj fp8");
+        }
+    } else if (c->attn_proj_kernel && c->attn_qk_kernel && vt_attn_qk_supported(S, C) && (lp % 8) == 0) {
+        // bf16 projections on attn_qk.hip's skeleton (mode 4: rows of one operand in registers, the other's rows streamed through LDS):
+        // q | k = x [Wq; Wk]^T + bqk -> [B][S][2C];  v^T = Wv x^T + bv -> [B][C][lp] (keys [S, round8(S)) zero)
+        AttnQkArgs pq{};
+        pq.mode = 4; pq.q = x16; pq.ldq = C; pq.qk_bs = (long long)S * C; pq.S = S; pq.C = C;
+        pq.k = w.wqk; pq.ldk = C; pq.k_bs = 0; pq.nk = 2 * C; pq.kbias = w.bqk;
+        pq.P = sc.qk; pq.ldp = 2 * C; pq.p_bs = (long long)S * 2 * C; pq.alpha = 1.f; pq.batch = B; pq.zeros = c->zeros; pq.row_bs = S;
+        auto split_for = [](long long qblocks, int nkt) { int n = 1; while (n < nkt && qblocks * n < 512) n *= 2; return n < nkt ? n : nkt; };
+        pq.nsplit = split_for((long long)B * ((S + 255) / 256), (2 * C + 63) / 64);
+        AttnQkArgs pv{};
+        pv.mode = 4; pv.q = w.wv; pv.ldq = C; pv.qk_bs = 0; pv.S = C; pv.C = C; pv.qbias = w.bv;
+        pv.k = x16; pv.ldk = C; pv.k_bs = (long long)S * C; pv.nk = S;
+        pv.P = sc.vt; pv.ldp = lp; pv.p_bs = (long long)C * lp; pv.alpha = 1.f; pv.batch = B; pv.zeros = c->zeros; pv.row_bs = C;
+        pv.nsplit = split_for((long long)B * ((C + 255) / 256), (S + 63) / 64);
+        if (c->profiling) {
+            vt_context::ProfRec r0, r1;
+            r0.e0 = c->next_event(); r0.e1 = c->next_event(); r1.e0 = c->next_event(); r1.e1 = c->next_event();
+            if (!r0.e0 || !r0.e1 || !r1.e0 || !r1.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+            r0.flops = 2.0 * B * (double)S * 2 * C * C; r1.flops = 2.0 * B * (double)S * C * C;
+            r0.cfg = r1.cfg = VT_PROF_PROJ_BF16;
+            HIPCK(c, hipEventRecord(r0.e0, s), "hipEventRecord");
+            HIPCK(c, vt_launch_attn_qk(pq, s), "attn qk proj");
+            HIPCK(c, hipEventRecord(r0.e1, s), "hipEventRecord");
+            HIPCK(c, hipEventRecord(r1.e0, s), "hipEventRecord");
+            HIPCK(c, vt_launch_attn_qk(pv, s), "attn v proj");
+            HIPCK(c, hipEventRecord(r1.e1, s), "hipEventRecord");
+            c->prof.push_back(r0); c->prof.push_back(r1);
+        } else {
+            HIPCK(c, vt_launch_attn_qk(pq, s), "attn qk proj");
+            HIPCK(c, vt_launch_attn_qk(pv, s), "attn v proj");
         }
     } else {
     // q | k = x Wqk^T + bqk  -> [B][S][2C]
@@ -1519,6 +1551,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 11) { c->fp8 = value != 0; return VT_OK; }
     if (flag == 16) { if ((value & 3) == 3 || value < 0 || value > 7) return c->fail(VT_ERR_INVALID, "vt_set_flag(16): tile shape 0..2 (+4: every layer)"); c->fp8_tile = value; return VT_OK; }
     if (flag == 12) { c->attn_pv_kernel = value != 0; return VT_OK; }
+    if (flag == 17) { c->attn_proj_kernel = value != 0; return VT_OK; }
     if (flag == 13) { c->s2_halo = value != 0; return VT_OK; }
     if (flag == 14) { c->attn_fp8 = value != 0; return VT_OK; }
     if (flag == 15) { c->proj_fp8 = value != 0; return VT_OK; }

@@ -59,8 +59,9 @@ constexpr int VT_PROF_ATTN_PV8 = 16;
 constexpr int VT_PROF_S2_HALO_FP8 = 17;  // stride-2 phase-plane conv on e4m3 operands (conv3x3_s2_halo_fp8.hip)
 constexpr int VT_PROF_PROJ_FP8 = 18;     // fp8 mode's q | k and v projections (attn_fp8.hip, proj_fp8_kernel)
 constexpr int VT_PROF_HALO_FP8_C128 = 19; // the fp8 halo conv's launches with Cin <= 128 (18 K-steps per tile), same kernel name as slot 11: tools read them apart
-constexpr int VT_PROF_GN_APPLY = 20;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
-constexpr int VT_NUM_PROF_SLOTS = 21;
+constexpr int VT_PROF_PROJ_BF16 = 20;    // bf16 q | k and v^T projections on attn_qk_kernel<4> (round 4)
+constexpr int VT_PROF_GN_APPLY = 21;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 22;
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
@@ -80,6 +81,11 @@ struct AttnQkArgs {
     // key tiles [i n / 4, (i + 1) n / 4) -- which attn_pv adds in a fixed order and inverts; nsplit = 2 or 4 spreads the segments of a
     // query block over that many workgroups (small grids: batch 1 at 1024^2 has 64 query blocks for 256 CUs) without changing a bit
     int nsplit; long long split_stride;
+    // mode 4 (round 4): the same skeleton as a LINEAR layer of K = 512 -- P[b][row][key] = bf16(alpha * q[row] . k[key] + kbias[key] + qbias[row]),
+    // rows = S rows of q (batch stride qk_bs), keys = nk rows of k [nk][ldk] (batch stride k_bs; 0 = shared weights), columns [nk, ldp rounded
+    // to the 64-key tile) written as 0; nsplit (any value >= 1) spreads a row block's key tiles over that many workgroups.  The attention's
+    // q | k projection (rows = tokens, keys = [Wq; Wk]) and v^T projection (rows = Wv, keys = tokens) run on it instead of the generic GEMM.
+    int nk, ldk; long long k_bs; const float* kbias; const float* qbias;
 };
 bool vt_attn_qk_supported(int S, int C);
 hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s);

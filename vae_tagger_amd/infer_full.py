@@ -17,6 +17,7 @@ stay within 1e-2 of the default path's):
 Reference: infer_full.py:16-71 (load_models), :73-141 (infer_and_classify), :143-186 (flags).
 """
 import argparse
+import contextlib
 import json
 import os
 from pathlib import Path
@@ -99,8 +100,10 @@ def summarize(conf_row, idx_row, tag_names, threshold):
             "avg_confidence_top5": float(f"{sum(top5) / 5:.4f}")}      # always divides by 5, like the reference
 
 
-def _entries_from_summary(summary, conf, idx, tag_names):
-    """JSON entries from the host arrays of the device-side summary (formatting only).  Raises FloatingPointError on non-finite confidences."""
+def _entries_from_summary(summary, conf, idx, tag_names, copy_stream=None):
+    """JSON entries from the host arrays of the device-side summary (formatting only).  Raises FloatingPointError on non-finite confidences.
+    `copy_stream`: the stream a longer prefix is fetched on (the pipelined loop passes one of its own, so that the copy of batch n's finished
+    arrays does not queue behind batch n + 1's kernels on the compute stream)."""
     top_conf, top_idx, stats = summary
     out = []
     for b in range(stats.shape[0]):
@@ -111,7 +114,8 @@ def _entries_from_summary(summary, conf, idx, tag_names):
         if count <= top_conf.shape[1]:
             cs, ix = top_conf[b, :count], top_idx[b, :count]
         else:                                       # rare: more tags above the threshold than the summary carries
-            cs, ix = conf[b, :count].cpu().numpy(), idx[b, :count].cpu().numpy()
+            with torch.cuda.stream(copy_stream) if copy_stream is not None else contextlib.nullcontext():
+                cs, ix = conf[b, :count].cpu().numpy(), idx[b, :count].cpu().numpy()
         predicted = [{"tag": tag_names[int(i)], "confidence": float(f"{float(c):.4f}")} for c, i in zip(cs, ix)]
         out.append({"predicted_tags": predicted, "total_tags_above_threshold": count,
                     "max_confidence": float(f"{mx:.4f}"), "avg_confidence_top5": float(f"{avg5:.4f}")})
@@ -168,6 +172,7 @@ class _Tagger:
         self.fp8 = bool(fp8)            # current numeric mode of the context
         self.fp32_res = False
         self.epoch = 0                  # bumped by every permanent mode switch: batches enqueued before it are redone
+        self.copy_stream = torch.cuda.Stream(device=pipe.device)
         if self.fp8:
             pipe.set_fp8(True)
 
@@ -272,7 +277,9 @@ class _Tagger:
             rec["ev"].synchronize()
             if rec["epoch"] == self.epoch and int(rec["word"][0]) == 0:
                 try:
-                    entries = _entries_from_summary(self.pipe.unpack_summary(rec["host"], rec["K"]), rec["conf"], rec["idx"], self.tag_names)
+                    # (the event has passed: conf / idx are final, so a longer prefix can be copied on a stream that does not wait for batch n + 1)
+                    entries = _entries_from_summary(self.pipe.unpack_summary(rec["host"], rec["K"]), rec["conf"], rec["idx"], self.tag_names,
+                                                    self.copy_stream)
                     return [(p, e, rec["fp8"]) for p, e in zip(rec["names"], entries)], 0
                 except Exception:  # noqa: BLE001
                     pass
