@@ -51,6 +51,9 @@ def parse():
     p.add_argument("--fp8", action="store_true",
                    help="BASELINE configs[4]: the 3x3 convs of the resnet / downsample stack and the attention's Q.K^T / P.V on fp8 (e4m3) "
                         "operands / fp8 MFMA (vt_set_flag 11); opt-in mode, logits within 1e-2 of the CPU reference, latents ~1e-1")
+    p.add_argument("--f16", action="store_true",
+                   help="fp16 instead of bf16 MFMA operands for the convolutions (vt_set_flag 18): the precision mode -- latents ~6x closer to the "
+                        "fp32 reference for a few per cent of the images/s; not BASELINE.json's dtype, never the default line")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-also", action="store_true", help="skip the configs[4] / configs[3] legs attached to the default run's line")
     p.add_argument("--generic-conv", action="store_true", help="A/B: disable the halo-tile 3x3 kernel")
@@ -255,6 +258,9 @@ def main():
         pipe.ctx.call("vt_set_flag", 11, 1)
         if a.encode_only:
             vae._context().call("vt_set_flag", 11, 1)       # (the encode-only leg runs on the VAE mirror's own context)
+    if a.f16:
+        pipe.set_fp16_operands(True)
+        vae._context().call("vt_set_flag", 18, 1)
     for fv in a.flag:
         f, v = fv.split("=")
         pipe.ctx.call("vt_set_flag", int(f), int(v))
@@ -430,11 +436,12 @@ def main():
             "metric": ("images/sec encode+tag, bucketed 512..1024 bf16" if a.bucketed else
                        "images/sec encode+tag, 1024^2 bf16" if not a.encode_only else "images/sec encode only, 1024^2 bf16").replace(
                            "bf16", "fp8 (3x3 convs, attention GEMMs, q|k / v projections; to_out, conv_in / conv_out bf16)" if a.fp8 else "bf16").replace(
-                           "1024^2", "1024^2" if (a.height, a.width) == (1024, 1024) else f"{a.width}x{a.height}"),
+                           "1024^2", "1024^2" if (a.height, a.width) == (1024, 1024) else f"{a.width}x{a.height}").replace(
+                           "bf16", "fp16 conv operands (attention bf16)" if a.f16 else "bf16"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_step_without_events": round(elapsed_plain / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8" if a.fp8 else ("f16" if a.f16 else "bf16"), "data": "synthetic",
             "config": cfg, "roofline": roof, "hbm_pass": hbm, "power": power_main,
             # the figure of merit under the 1400-W cap: socket power of the untraced steps / their images per second
             "joules_per_image": None if not power_main else round(power_main["socket_w_median"] / (images_per_step / world * a.steps / elapsed_plain), 3),
@@ -442,7 +449,7 @@ def main():
 
     # ---- the other single-GPU configs of BASELINE.json on the same pipeline, attached to the ONE line as "also" (default run only):
     # configs[4] per GPU (fp8 mode, same batch) and configs[3] (bucketed batches); ~2 s of GPU time, headline keys untouched
-    default_run = (world == 1 and not (a.fp8 or a.bucketed or a.encode_only or a.generic_conv or a.no_occ2 or a.flag)
+    default_run = (world == 1 and not (a.fp8 or a.f16 or a.bucketed or a.encode_only or a.generic_conv or a.no_occ2 or a.flag)
                    and not a.no_also)
     also_f8_logits = also_f8_idx = None
     if default_run:

@@ -164,6 +164,13 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         GroupNorm partials are per tile, so their merge order -- the last bits of the statistics -- follows the shape).
  * flag 17: 1 (default) = the attention's bf16 q | k and v^T projections run on attn_qk.hip's skeleton (mode 4: one operand's rows in
  *         registers, the other's streamed through LDS, bias + bf16 store in the epilogue); 0 = the generic GEMM (conv_gemm.hip).
+ * flag 18: 1 = fp16 instead of bf16 MFMA operands for the convolutions (GroupNorm outputs, the 16-bit operand copies and the packed
+ *         weights carry fp16 bits: the same 2 B per element, 11 significand bits instead of 8; v_mfma_f32_16x16x32_f16).  Latents move
+ *         ~6x closer to the fp32 reference (max |dlatent| 1.5e-3 instead of 1e-2 .. 2e-2 on smooth pictures, where bf16's rounding
+ *         errors add coherently); the matrix pipe draws more power on fp16 data, about 4 % of the images/s.  Values must fit fp16
+ *         (|x| <= 65504: GroupNorm + SiLU outputs and weights do; an overflow shows as status bit 0).  Ignored in fp8 mode (flag 11);
+ *         needs the default kernel selection (flags 0, 2, 3, 13 at their defaults), other settings keep bf16 for the convs they affect.
+ *         The attention keeps bf16 (its softmax numerators need bf16's range).  0 (default) = bf16 operands, BASELINE.json's dtype.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

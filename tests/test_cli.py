@@ -19,8 +19,8 @@ def _flags(parser):
 
 def test_cli_flags_match_reference():
     assert REF_FULL_FLAGS <= _flags(infer_full.build_parser())
-    assert _flags(infer_full.build_parser()) - REF_FULL_FLAGS == {"--batch_size", "--device_resize", "--host_resize", "--workers", "--serial", "--fp8"}
-    assert _flags(infer_vae.build_parser()) - REF_VAE_FLAGS == {"--batch_size", "--host_resize", "--workers"}
+    assert _flags(infer_full.build_parser()) - REF_FULL_FLAGS == {"--batch_size", "--device_resize", "--host_resize", "--workers", "--serial", "--fp8", "--fp16_operands"}
+    assert _flags(infer_vae.build_parser()) - REF_VAE_FLAGS == {"--batch_size", "--host_resize", "--workers", "--fp16_operands"}
     a = infer_full.build_parser().parse_args(["--vae_checkpoint", "v", "--decoder_checkpoint", "d", "--image_path", "i",
                                               "--tags_csv_path", "t"])
     assert (a.resolution, a.confidence_threshold, a.output_dir, a.use_attention, a.use_cross_attention) == \

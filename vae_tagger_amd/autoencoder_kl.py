@@ -128,6 +128,11 @@ class AutoencoderKL(HipModule):
     def set_fp32_residual(self, on=True):
         self._context().call("vt_set_flag", 4, 0 if on else 1)
 
+    def set_fp16_operands(self, on=True):
+        """fp16 instead of bf16 MFMA operands for the convolutions (vt_set_flag 18): latents ~6x closer to the fp32 reference -- what a
+        smooth picture needs to stay inside 1e-2 -- for about 4 % of the images/s."""
+        self._context().call("vt_set_flag", 18, 1 if on else 0)
+
     # -- diffusers surface ---------------------------------------------------------------------------
     @torch.no_grad()
     def encode(self, x, return_dict=True):

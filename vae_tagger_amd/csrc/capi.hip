@@ -25,6 +25,8 @@ struct HostTensor {
 struct ConvW {
     const bf16_t* w = nullptr; const bf16_t* wp = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0;   // w: [cout][tap][cin]; wp: halo-kernel packing
     const bf16_t* wp2 = nullptr;        // stride-2 phase-plane kernel's packing (conv3x3_s2_halo.hip)
+    // the same three layouts holding fp16 bits (vt_set_flag 18: fp16 operands for the convs); w16 only for Cout <= 32 (conv_out)
+    const bf16_t* w16 = nullptr; const bf16_t* wp16 = nullptr; const bf16_t* wp2_16 = nullptr;
     const unsigned char* wp8 = nullptr; const float* mult8 = nullptr;   // fp8 halo kernel: e4m3 weights / per-cout (scale / act_scale)
     const unsigned char* w8g = nullptr; const float* mult8g = nullptr;  // fp8 generic GEMM (stride-2 convs): [cout][tap][cin] e4m3 / per-cout scale (input scale 1)
     const unsigned char* wp8s2 = nullptr;                                // fp8 stride-2 phase-plane kernel's packing (same scales: mult8g)
@@ -34,6 +36,7 @@ struct ResnetW {
     NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0;
     // conv_shortcut fused into conv2's launch (Conv3x3Args::scW): [cin/32][cout][32] bf16, interleaved cout rows; bias c2 + sc
     const bf16_t* sc_wp = nullptr; const float* b_c2sc = nullptr;
+    const bf16_t* sc_wp16 = nullptr;     // sc_wp holding fp16 bits (vt_set_flag 18)
     const bf16_t* sc_wp8 = nullptr;      // the same for the fp8 conv2: rows in its cout order, values divided by conv2's mult[cout]
 };
 struct AttnW { NormW gn; const bf16_t *wqk = nullptr, *wv = nullptr, *wo = nullptr; const float *bqk = nullptr, *bv = nullptr, *bo = nullptr; int c = 0;
@@ -65,6 +68,8 @@ uint16_t f2bf(float f) {
     return (uint16_t)(u >> 16);
 }
 float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+// float -> IEEE fp16 bits, round to nearest even (the compiler's own conversion: _Float16 is a host type too)
+uint16_t f2h(float f) { const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
 float h2f(uint16_t h) {
     const uint32_t s = (h >> 15) & 1, e = (h >> 10) & 31, m = h & 1023;
     uint32_t u;
@@ -151,6 +156,7 @@ struct vt_context {
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
     int proj_fp8 = 1;               // vt_set_flag(ctx, 15, v): with the fp8 attention, the q | k and v projections on e4m3 operands too, writing q8 | k8 and v8^T directly
     int attn_fp8 = 1;               // vt_set_flag(ctx, 14, v): in fp8 mode (flag 11) Q.K^T and P.V run on e4m3 operands too (attn_fp8.hip)
+    int f16_ops = 0;                // vt_set_flag(ctx, 18, v): fp16 instead of bf16 operands for the convs (same 2 B, 11 significand bits instead of 8)
     int attn_proj_kernel = 1;       // vt_set_flag(ctx, 17, v): the bf16 q | k and v^T projections on attn_qk.hip's skeleton (mode 4) instead of the generic GEMM
     int fp8_tile = 0;               // vt_set_flag(ctx, 16, v): fp8 halo conv tile shape = v & 3 (0: 8 x 32 px, 4 waves, two workgroups per CU; 1: 16 x 32 px;
                                     // 2: 8 x 64 px, 8 waves, one per CU) on the layers with Cin <= 128, or on every layer with v & 4
@@ -251,6 +257,34 @@ int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, C
         out->wp2 = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
         if (!out->wp2) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
     }
+    {
+        // fp16-operand mode (vt_set_flag 18): the same layouts with fp16 bits -- 11 significand bits of every weight instead of 8
+        std::vector<uint16_t> ph(p.size()), hp(p.size());
+        for (int o = 0; o < cout; ++o)
+            for (int i = 0; i < cin; ++i)
+                for (int t = 0; t < k * k; ++t)
+                    ph[((size_t)o * k * k + t) * cin + i] = f2h(w->v[((size_t)o * cin + i) * k * k + t]);
+        if (k == 3 && cout <= 32) {
+            out->w16 = (const bf16_t*)c->upload(ph.data(), ph.size() * 2);
+            if (!out->w16) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+        }
+        if (out->wp) {
+            for (int o = 0; o < cout; ++o)
+                for (int t = 0; t < 9; ++t)
+                    for (int i = 0; i < cin; ++i)
+                        hp[(((size_t)(i >> 5) * 9 + vt_halo_step_of_tap(t)) * cout + ((o & ~63) + vt_halo_row_of_cout(o & 63))) * 32 + (i & 31)] = ph[((size_t)o * 9 + t) * cin + i];
+            out->wp16 = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
+            if (!out->wp16) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+        }
+        if (out->wp2) {
+            for (int o = 0; o < cout; ++o)
+                for (int t = 0; t < 9; ++t)
+                    for (int i = 0; i < cin; ++i)
+                        hp[(((size_t)(i >> 5) * 9 + vt_s2_step_of_tap(t)) * cout + ((o & ~63) + vt_halo_row_of_cout(o & 63))) * 32 + (i & 31)] = ph[((size_t)o * 9 + t) * cin + i];
+            out->wp2_16 = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
+            if (!out->wp2_16) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+        }
+    }
     if (k == 3 && vt_conv3x3_halo_fp8_supported(cin, cout)) {
         std::vector<uint8_t> p8; std::vector<float> m8;
         pack_conv_fp8(w->v.data(), cout, cin, &p8, &m8);
@@ -313,7 +347,11 @@ int get_resnet(vt_context* c, const std::string& p, int cin, int cout, ResnetW* 
         for (int o = 0; o < cout; ++o) bb[o] = b2->v[o] + bs->v[o];
         r->sc_wp = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
         r->b_c2sc = (const float*)c->upload(bb.data(), bb.size() * 4);
-        if (!r->sc_wp || !r->b_c2sc) return c->fail(VT_ERR_HIP, "upload failed for %s.conv_shortcut", p.c_str());
+        for (int o = 0; o < cout; ++o)
+            for (int i = 0; i < cin; ++i)
+                hp[((size_t)(i >> 5) * cout + ((o & ~63) + vt_halo_row_of_cout(o & 63))) * 32 + (i & 31)] = f2h(w->v[(size_t)o * cin + i]);
+        r->sc_wp16 = (const bf16_t*)c->upload(hp.data(), hp.size() * 2);
+        if (!r->sc_wp || !r->b_c2sc || !r->sc_wp16) return c->fail(VT_ERR_HIP, "upload failed for %s.conv_shortcut", p.c_str());
         if (r->c2.wp8) {
             // fp8 conv2: its epilogue multiplies the accumulator by mult[cout] = scale / 8, so the shortcut rows carry 1 / mult
             const HostTensor* w2 = c->find(p + ".conv2.weight");
@@ -431,7 +469,7 @@ struct GnState {
 
 // y = act(GroupNorm(x)) as bf16 rows.  Uses epilogue-produced partials when present.
 int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int B, int HW, const NormW& n, int groups, int silu, bf16_t* y,
-           GnState& g, hipStream_t s, bool out_fp8 = false) {
+           GnState& g, hipStream_t s, bool out_fp8 = false, bool out_f16 = false /* y holds fp16 bits: the consumer conv runs on fp16 operands */) {
     const float o8 = out_fp8 ? FP8_ACT_SCALE : 0.f;       // y then holds e4m3(8 y), one byte per element
     int parts = g.parts;
     if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, xdt, B, HW, n.c, groups, g.partial, &parts, s), "gn_stats");
@@ -444,25 +482,35 @@ int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int
         r.flops = (double)B * HW * n.c * ((xdt == 1 ? 4.0 : 2.0) + (out_fp8 ? 1.0 : 2.0));     // algorithmic bytes: one read + one bf16 / fp8 write
         r.cfg = VT_PROF_GN_APPLY;
         HIPCK(c, hipEventRecord(r.e0, s), "hipEventRecord");
-        HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s, o8, c->status), "gn_apply");
+        HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s, o8, c->status, out_f16), "gn_apply");
         HIPCK(c, hipEventRecord(r.e1, s), "hipEventRecord");
         c->prof.push_back(r);
         return VT_OK;
     }
-    HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s, o8, c->status), "gn_apply");
+    HIPCK(c, vt_launch_gn_apply(x, xdt, g.ss, y, B, HW, n.c, silu, s, o8, c->status, out_f16), "gn_apply");
     return VT_OK;
 }
+
+// fp16-operand mode (vt_set_flag 18): does THIS conv multiply fp16 operands?  A 16-bit operand tensor carries fp16 bits exactly when its
+// consumer says yes here, so producer and consumer sites ask the same question.  Not in fp8 mode; the kernels that have an fp16 form are the
+// default halo tile (plain input), the stride-2 phase-plane kernel and the 32-cout GEMM tile (conv_out).
+bool conv_f16(const vt_context* c, const ConvW& w, int stride, bool has_sc) {
+    if (!c->f16_ops || c->fp8 || w.k != 3) return false;
+    if (stride == 2) return c->s2_halo && w.wp2_16 != nullptr;
+    return c->use_halo_conv && w.wp && w.wp16 && !c->fuse_gn_apply && vt_conv3x3_halo_f16_supported(w.cout, c->halo_occ2, has_sc ? 1 : 0);
+}   // (conv_out, the one conv on the 32-cout GEMM tile, is decided where it is launched)
 
 // `gn`: if non-null, the epilogue also writes GroupNorm partials of the output (cpg = cout / groups)
 // `xnorm_f32` / `ss`: when ss is given the conv input is silu(x*scale + shift) with x = xnorm_f32 (fp32) or x (bf16),
 // fused into the halo staging (only valid when norm_conv_fusable()).
 // `res` / `oh` are the residual-stream tensors (input to add, output to write): fp32 when rdt == 1, fp16 when rdt == 2.
 // `sc`: a 1x1 conv of sc->x fused into the halo launch (resnet conv_shortcut); then `res` must be null.
-struct ScFuse { const bf16_t* x; const bf16_t* wp; const float* bias; int cin; const bf16_t* wp8; };
+struct ScFuse { const bf16_t* x; const bf16_t* wp; const float* bias; int cin; const bf16_t* wp8; const bf16_t* wp16; };
 int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int Win, int stride, int pad, int Hout,
              int Wout, const void* res, void* oh, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32,
              const float* xnorm_f32 = nullptr, const float* ss = nullptr, int rdt = 1, const ScFuse* sc = nullptr,
-             bool x_fp8 = false, bool o16_e4m3 = false) {
+             bool x_fp8 = false, bool o16_e4m3 = false, bool x_f16 = false /* x (and sc->x) hold fp16 bits: conv_f16() of this conv */,
+             bool o16_f16 = false /* o16 is written as fp16 bits: conv_f16() of ITS consumer */) {
     const float* res32 = rdt == 1 ? (const float*)res : nullptr;
     const f16_t* res16 = rdt == 2 ? (const f16_t*)res : nullptr;
     float* o32 = rdt == 1 ? (float*)oh : nullptr;
@@ -535,8 +583,8 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     }
     if (c->s2_halo && w.wp2 && w.k == 3 && stride == 2 && pad == 0 && Hout == Hin / 2 && Wout == Win / 2 && !res16 && !ss && !sc && !xnorm_f32) {
         Conv3x3S2Args h{};
-        h.X = x; h.Wp = w.wp2; h.bias = w.b; h.res = res32; h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
-        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
+        h.X = x; h.Wp = x_f16 ? w.wp2_16 : w.wp2; h.bias = w.b; h.res = res32; h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
+        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout; h.f16 = x_f16; h.out16_f16 = o16_f16;
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_s2_tiles(Hout, Wout); }
         if (c->profiling) {
             vt_context::ProfRec r;
@@ -556,14 +604,15 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     if (c->use_halo_conv && w.wp && w.k == 3 && stride == 1 && pad == 1 && Hout == Hin && Wout == Win) {
         Conv3x3Args h{};
         h.X = xnorm_f32 ? nullptr : x; h.Xf32 = xnorm_f32; h.scale_shift = ss;
-        h.Wp = w.wp; h.bias = w.b; h.res = res32; h.res_f16 = res16; h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
-        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
-        if (sc) { h.scX = sc->x; h.scW = sc->wp; h.scCin = sc->cin; h.bias = sc->bias; }
+        h.Wp = x_f16 ? w.wp16 : w.wp; h.bias = w.b; h.res = res32; h.res_f16 = res16; h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
+        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout; h.f16 = x_f16; h.out16_f16 = o16_f16;
+        if (sc) { h.scX = sc->x; h.scW = x_f16 ? sc->wp16 : sc->wp; h.scCin = sc->cin; h.bias = sc->bias; }
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout, ss ? (xnorm_f32 ? 1 : 2) : 0, c->halo_occ2, sc != nullptr); }
         HIPCK(c, launch_halo(c, h, s), "conv3x3_halo");
         return VT_OK;
     }
     if (ss || sc) return c->fail(VT_ERR_STATE, "internal: fused norm / shortcut requested for a conv the halo kernel cannot run");
+    if (x_f16 || o16_f16) return c->fail(VT_ERR_STATE, "internal: fp16 operands requested for a conv on the generic GEMM");
     ConvGemmArgs a{};
     a.X = x; a.W = w.w; a.bias = w.b; a.res = res32; a.res_f16 = res16; a.out_f32 = o32; a.out_f16 = oh16; a.out_bf16 = o16; a.zeros = c->zeros;
     a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cin = w.cin; a.Cout = w.cout; a.Wrows = w.cout;
@@ -589,13 +638,14 @@ bool norm_conv_fusable(const vt_context* c, const ConvW& w, int cin) {
 // x: the tensor to normalise (xdt 0 = bf16 conv output, 1 = fp32 / 2 = fp16 residual stream); res / oh: residual in / out (rdt).
 int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, int xdt, int B, int H, int W,
                   int groups, bf16_t* act, const void* res, void* oh, bf16_t* o16, GnState& gn, bool want_stats,
-                  hipStream_t s, int rdt, const ScFuse* sc = nullptr, bool o16_e4m3 = false) {
+                  hipStream_t s, int rdt, const ScFuse* sc = nullptr, bool o16_e4m3 = false, bool o16_f16 = false) {
     const bool f8 = c->fp8 && w.wp8 && w.k == 3 && (!sc || sc->wp8);      // fp8 operands: the GroupNorm-apply pass writes e4m3, the conv reads it
     if (o16_e4m3 && !f8) return c->fail(VT_ERR_STATE, "internal: e4m3 output requested from a bf16 conv");
     if (f8 || xdt == 2 || !norm_conv_fusable(c, w, n.c)) {   // (the fused staging reads fp32 or bf16 only)
-        int r = run_gn(c, x, xdt, B, H * W, n, groups, 1, act, gn, s, f8);
+        const bool h16 = !f8 && conv_f16(c, w, 1, sc != nullptr);             // fp16-operand mode: the pass writes fp16, the conv multiplies fp16
+        int r = run_gn(c, x, xdt, B, H * W, n, groups, 1, act, gn, s, f8, h16);
         if (r) return r;
-        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt, sc, f8, o16_e4m3);
+        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt, sc, f8, o16_e4m3, h16, o16_f16);
     }
     if (sc) return c->fail(VT_ERR_STATE, "internal: fused shortcut with the fused-norm staging");
     int parts = gn.parts;
@@ -1256,11 +1306,11 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
     };
     // one ResnetBlock2D: h <- conv2(silu(gn(conv1(silu(gn(h)))))) + shortcut(h)
     // hb_e4m3: the stage's downsample conv runs on fp8 operands, so the block output for it is written as e4m3 instead of bf16
-    auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out, bool hb_e4m3 = false) -> int {
+    auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out, bool hb_e4m3 = false, bool hb_f16 = false) -> int {
         const int nxt = (cur + 1) % 3, scb = (cur + 2) % 3;
         const void* res = f32[cur];
         int rr;
-        ScFuse scf{h16_for_shortcut, rw.sc_wp, rw.b_c2sc, rw.cin, rw.sc_wp8};
+        ScFuse scf{h16_for_shortcut, rw.sc_wp, rw.b_c2sc, rw.cin, rw.sc_wp8, rw.sc_wp16};
         const ScFuse* sc = nullptr;
         if (rw.has_sc) {
             if (fuse_sc(rw)) {
@@ -1280,7 +1330,7 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
                                 c1h ? nullptr : tmid, gn, true, s, rdt))) return rr;
         if (want_bf16_out) {
             // the only consumer is the downsample conv (bf16 operand, no norm): skip the fp32 copy of h and the stats
-            return run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt, sc, hb_e4m3);
+            return run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt, sc, hb_e4m3, hb_f16);
         }
         if ((rr = run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, f32[nxt], nullptr, gn, true, s, rdt, sc))) return rr;
         cur = nxt;
@@ -1288,7 +1338,7 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
     };
 
     const bf16_t* h16 = nullptr;                   // bf16 copy of the current h, when one exists
-    bool hb_is_e4m3 = false;
+    bool hb_is_e4m3 = false, hb_is_f16 = false;
     for (size_t i = 0; i < e.stages.size(); ++i) {
         const StageW& st = e.stages[i];
         for (size_t j = 0; j < st.res.size(); ++j) {
@@ -1296,7 +1346,10 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             if (st.res[j].has_sc && !h16) return c->fail(VT_ERR_STATE, "internal: shortcut conv without a bf16 input");
             // fp8 mode: the last block of a stage hands its output to the stride-2 conv as e4m3 when both run on fp8 operands
             const bool down8 = last && st.has_down && c->fp8 && st.down.w8g && st.res[j].c2.wp8 && !st.res[j].has_sc;
-            if ((r = resnet(st.res[j], h16, last && st.has_down, down8))) return r;
+            // fp16-operand mode: the block output for the stride-2 conv carries fp16 bits when that conv multiplies fp16 (conv_f16)
+            const bool down16 = last && st.has_down && !down8 && conv_f16(c, st.down, 2, false);
+            if ((r = resnet(st.res[j], h16, last && st.has_down, down8, down16))) return r;
+            if (last) hb_is_f16 = down16;
             if (last) hb_is_e4m3 = down8;
             h16 = (last && st.has_down) ? hb : nullptr;
         }
@@ -1309,7 +1362,10 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             // before conv1 overwrites tmid; when the shortcut is fused into conv2 it must outlive conv1, so it goes to the
             // third rotating buffer (the block's `scb`, free now that no shortcut tensor is written)
             bf16_t* copy = !next_has_sc ? nullptr : (fuse_sc(e.stages[i + 1].res[0]) ? (bf16_t*)f32[(nxt + 2) % 3] : tmid);
-            if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], copy, s, &gn, e.groups, nullptr, nullptr, rdt, nullptr, hb_is_e4m3))) return r;
+            // ... and the bf16 copy for the next block's FUSED shortcut carries fp16 bits when that block's conv2 does
+            const bool copy16 = copy && fuse_sc(e.stages[i + 1].res[0]) && conv_f16(c, e.stages[i + 1].res[0].c2, 1, true);
+            if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], copy, s, &gn, e.groups, nullptr, nullptr, rdt, nullptr, hb_is_e4m3,
+                              false, hb_is_f16, copy16))) return r;
             h16 = copy;
             cur = nxt; h = ho; w = wo;
         }
@@ -1323,12 +1379,13 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
         cur = nxt;
     }
     if ((r = resnet(e.mid1, nullptr, false))) return r;
-    if ((r = run_gn(c, f32[cur], rdt, B, h * w, e.norm_out, e.groups, 1, act, gn, s))) return r;
+    const bool out16 = e.conv_out.cout <= 32 && e.conv_out.w16 && c->f16_ops && !c->fp8;      // fp16-operand mode: conv_out on the 32-cout GEMM tile's fp16 form
+    if ((r = run_gn(c, f32[cur], rdt, B, h * w, e.norm_out, e.groups, 1, act, gn, s, false, out16))) return r;
     {
         // conv_out -> moments; mode() = mean = first `latent` channels; optional * scaling + shift
         ConvGemmArgs a{};
         const ConvW& cw = e.conv_out;
-        a.X = act; a.W = cw.w; a.bias = cw.b; a.out_f32 = latent; a.zeros = c->zeros;
+        a.X = act; a.W = out16 ? cw.w16 : cw.w; a.f16 = out16; a.bias = cw.b; a.out_f32 = latent; a.zeros = c->zeros;
         a.Hin = a.Hout = h; a.Win = a.Wout = w; a.Cin = cw.cin; a.Cout = cw.cout; a.Wrows = cw.cout;
         a.ksize = 3; a.stride = 1; a.pad = 1; a.ldx = cw.cin; a.ldw = 9 * cw.cin; a.ldo = cw.cout;
         a.cout_keep = mode == 0 ? 2 * e.latent : e.latent;
@@ -1552,6 +1609,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 16) { if ((value & 3) == 3 || value < 0 || value > 7) return c->fail(VT_ERR_INVALID, "vt_set_flag(16): tile shape 0..2 (+4: every layer)"); c->fp8_tile = value; return VT_OK; }
     if (flag == 12) { c->attn_pv_kernel = value != 0; return VT_OK; }
     if (flag == 17) { c->attn_proj_kernel = value != 0; return VT_OK; }
+    if (flag == 18) { c->f16_ops = value != 0; return VT_OK; }
     if (flag == 13) { c->s2_halo = value != 0; return VT_OK; }
     if (flag == 14) { c->attn_fp8 = value != 0; return VT_OK; }
     if (flag == 15) { c->proj_fp8 = value != 0; return VT_OK; }

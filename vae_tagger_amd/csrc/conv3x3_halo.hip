@@ -61,14 +61,21 @@ extern "C" int vt_debug_halo_stamps_nth(unsigned long long* buf, int H, int Cin,
 
 namespace {
 
-// HALO_F16 (experiment, tools/bench_halo_power.py): the same instruction stream with v_mfma_f32_16x16x32_f16 on the operand bits
+// F16: the same instruction stream with v_mfma_f32_16x16x32_f16 on fp16 operand bits (vt_set_flag 18: 11 significand bits instead of
+// bf16's 8 at the same 2 B per element; -DHALO_F16 forces it for the operand-precision experiment of tools/bench_f16_operands.py)
+template <bool F16>
 __device__ __forceinline__ f32x4 halo_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
 #ifdef HALO_F16
-    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    constexpr bool H = true;
 #else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    constexpr bool H = F16;
 #endif
+    if constexpr (H) {
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
 }
 
 constexpr int HB = 64;        // bytes per LDS row (32 bf16)
@@ -129,9 +136,10 @@ __device__ __forceinline__ void wait_vmcnt_tied1(int n, V& r0) {
 //                VALU + stores, statistics; tools/stamp_halo.py) and the other workgroup's MFMAs run under them;
 //   <4,2,0,4,4>  8 waves x 128 VGPRs, same tile, two workgroups per CU (the earlier form of the same idea);
 //   <2,4,.,8,6> / <4,2,.,8,6>  8 waves x 256 VGPRs, 256 / 128 couts, one workgroup per CU (and the only shapes of XT != 0).
-template <int WP, int WC, int XT, int TPW, int NW>
+template <int WP, int WC, int XT, int TPW, int NW, bool F16 = false>
 __global__ __launch_bounds__(64 * WP * WC, TPW == 4 ? 4 : 2)
 void conv3x3_halo_kernel(const Conv3x3Args a) {
+    static_assert(!F16 || XT == 0, "fp16 operands: plain-input tiles only");
     constexpr int NWV = WP * WC;                 // waves per workgroup
     constexpr int NT = 64 * NWV;
     static_assert((NWV == 8 && (TPW == 8 || (TPW == 4 && XT == 0))) || (NWV == 4 && TPW == 8 && XT == 0),
@@ -427,7 +435,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 for (int j = 0; j < TP; ++j) {
 #pragma unroll
                     for (int i = 0; i < TC; ++i)
-                        acc[i][j] = halo_mfma(wfc[i], xr[j], acc[i][j]);
+                        acc[i][j] = halo_mfma<F16>(wfc[i], xr[j], acc[i][j]);
                     if (has_next) {
                         const int rel = (j + dy_n) * HWID + dx_n;
                         xr[j] = *(const bf16x8*)(xs_n + xaddr(rel & 7) + rel * HB);     // its last reader has issued
@@ -468,7 +476,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 for (int j = 0; j < TP; ++j) {
 #pragma unroll
                     for (int i = 0; i < TC; ++i)
-                        acc[i][j] = halo_mfma(wfc[i], xr[j + dy], acc[i][j]);
+                        acc[i][j] = halo_mfma<F16>(wfc[i], xr[j + dy], acc[i][j]);
                     if (next_group) {                                      // rows whose last reader has just issued
                         if (dy == 0 && j == 0) refill(0);
                         if (dy == 1 && j == 0) refill(1);
@@ -527,7 +535,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < TC; ++i)
-                        acc[i][jh + j] = halo_mfma(wf[i], xf[j], acc[i][jh + j]);
+                        acc[i][jh + j] = halo_mfma<F16>(wf[i], xf[j], acc[i][jh + j]);
             }
             __builtin_amdgcn_s_setprio(0);
             if constexpr (STAGE) {
@@ -593,7 +601,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int i = 0; i < TC; ++i)
-                            acc[i][jh + j] = halo_mfma(wf[i], xf[j], acc[i][jh + j]);
+                            acc[i][jh + j] = halo_mfma<F16>(wf[i], xf[j], acc[i][jh + j]);
                 }
             }
         }
@@ -672,6 +680,13 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
         if (a.out_bf16) {
 #pragma unroll
             for (int i = 0; i < TC; i += 2) {
+                if (a.out16_f16) {                             // the operand copy carries fp16 bits when its consumer runs on fp16 operands
+                    typedef _Float16 f16x8o __attribute__((ext_vector_type(8)));
+                    f16x8o h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { h[r] = (f16_t)acc[i][j][r]; h[4 + r] = (f16_t)acc[i + 1][j][r]; }
+                    *(f16x8o*)((f16_t*)a.out_bf16 + o + 4 * i) = h;
+                } else {
                 bf16x8 h;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { h[r] = (bf16_t)acc[i][j][r]; h[4 + r] = (bf16_t)acc[i + 1][j][r]; }
@@ -680,6 +695,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
 #else
                 *(bf16x8*)(a.out_bf16 + o + 4 * i) = h;
 #endif
+                }
             }
         }
     }
@@ -705,7 +721,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
 #endif
 }
 
-template <int WP, int WC, int XT, int TPW, int NW = NW_DEFAULT>
+template <int WP, int WC, int XT, int TPW, int NW = NW_DEFAULT, bool F16 = false>
 hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
     constexpr int ROWS = WP * TPW, BC = WC * 64, NWV = WP * WC;
     constexpr int HROWS = (ROWS + 2) * HWID;
@@ -713,7 +729,7 @@ hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
     const int smem = 2 * NXW * NWV * 16 * HB + NW * BC * HB + (XT ? a.Cin * 8 : 0);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> attr_done{0};
-    auto kern = conv3x3_halo_kernel<WP, WC, XT, TPW, NW>;
+    auto kern = conv3x3_halo_kernel<WP, WC, XT, TPW, NW, F16>;
     hipError_t ea = vt_once_per_device(attr_done, [&] { return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (ea != hipSuccess) return ea;
     const long long tiles = (long long)((a.W + TW - 1) / TW) * ((a.H + ROWS - 1) / ROWS);
@@ -789,6 +805,8 @@ int vt_conv3x3_halo_tiles(int H, int W, int Cout, int xt, int occ2, int has_sc) 
 int vt_conv3x3_halo_tiles_max(int H, int W) { return ((W + TW - 1) / TW) * ((H + 15) / 16); }
 
 bool vt_conv3x3_halo_supported(int Cin, int Cout) { return Cin >= 32 && (Cin % 32) == 0 && (Cout % 128) == 0; }
+// fp16-operand form (Conv3x3Args::f16): compiled for the default two-workgroups-per-CU tile on plain input
+bool vt_conv3x3_halo_f16_supported(int Cout, int occ2, int has_sc) { return halo_variant(Cout, 0, occ2, has_sc != 0) == HV_2208_4; }
 
 static int halo_xt(const Conv3x3Args& a) { return a.scale_shift ? (a.Xf32 ? 1 : 2) : 0; }
 
@@ -816,6 +834,8 @@ hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
     // input mode: raw bf16 (X), or GroupNorm+SiLU fused into the staging of an fp32 (Xf32) / bf16 (X) tensor
     const int xt = halo_xt(a);
     if (xt == 1 ? (a.X != nullptr) : (a.X == nullptr || a.Xf32 != nullptr)) return hipErrorInvalidValue;
+    if (a.f16 && (xt != 0 || halo_variant(a.Cout, xt, a.occ2, a.scX != nullptr) != HV_2208_4)) return hipErrorInvalidValue;   // fp16 operands: the default tile only
+    if (a.f16) return launch<2, 2, 0, 8, 4, true>(a, s);
     switch (halo_variant(a.Cout, xt, a.occ2, a.scX != nullptr)) {
         case HV_2208_4: return launch<2, 2, 0, 8, 4>(a, s);
         case HV_4204_4: return launch<4, 2, 0, 4, 4>(a, s);

@@ -80,6 +80,8 @@ __device__ __forceinline__ int opaque_s(int v) {
     return v;
 }
 
+// F16: X and Wp hold fp16 bits (v_mfma_f32_16x16x32_f16) -- the fp16-operand mode of the convs (vt_set_flag 18)
+template <bool F16>
 __global__ __launch_bounds__(NT, 2) void conv3x3_s2_halo_kernel(const Conv3x3S2Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xbase = smem;                    // NXB plane buffers
@@ -234,7 +236,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_s2_halo_kernel(const Conv3x3S2A
             for (int j = 0; j < TP; ++j) {
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[i], xr[two ? j + dy : j], acc[i][j], 0, 0, 0);
+                    if constexpr (F16) {
+                        typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8m, wfc[i]), __builtin_bit_cast(f16x8m, xr[two ? j + dy : j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[i], xr[two ? j + dy : j], acc[i][j], 0, 0, 0);
+                    }
                 // rows whose last reader has just issued are refilled with the next group's rows
                 if (two) {
                     if (dy == 0) { if (j == 0) refill(0, acc[TC - 1][j]); }
@@ -308,10 +315,17 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_s2_halo_kernel(const Conv3x3S2A
         if (a.out_bf16) {
 #pragma unroll
             for (int i = 0; i < TC; i += 2) {
-                bf16x8 h;
+                if (a.out16_f16) {                             // the copy carries fp16 bits when its consumer (a fused shortcut) runs on fp16 operands
+                    f16x8 h;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { h[r] = (bf16_t)acc[i][j][r]; h[4 + r] = (bf16_t)acc[i + 1][j][r]; }
-                *(bf16x8*)(a.out_bf16 + o + 4 * i) = h;
+                    for (int r = 0; r < 4; ++r) { h[r] = (f16_t)acc[i][j][r]; h[4 + r] = (f16_t)acc[i + 1][j][r]; }
+                    *(f16x8*)((f16_t*)a.out_bf16 + o + 4 * i) = h;
+                } else {
+                    bf16x8 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { h[r] = (bf16_t)acc[i][j][r]; h[4 + r] = (bf16_t)acc[i + 1][j][r]; }
+                    *(bf16x8*)(a.out_bf16 + o + 4 * i) = h;
+                }
             }
         }
     }
@@ -354,7 +368,11 @@ hipError_t vt_launch_conv3x3_s2(const Conv3x3S2Args& a, hipStream_t s) {
     if ((long long)a.H * a.W * a.Cin >= (1LL << 31)) return hipErrorInvalidValue;        // 32-bit per-image offsets
     if ((long long)(a.Cin / 32) * 9 * a.Cout * 32 >= (1LL << 31)) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> attr_done{0};
-    hipError_t ea = vt_once_per_device(attr_done, [&] { return hipFuncSetAttribute((const void*)conv3x3_s2_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); });
+    hipError_t ea = vt_once_per_device(attr_done, [&] {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_s2_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        return e;
+    });
     if (ea != hipSuccess) return ea;
     Conv3x3S2Args k = a;
     k.Ho = a.H / 2; k.Wo = a.W / 2;                       // pad (0,1,0,1), 3x3, stride 2: floor((H + 1 - 3) / 2) + 1
@@ -366,6 +384,7 @@ hipError_t vt_launch_conv3x3_s2(const Conv3x3S2Args& a, hipStream_t s) {
         return (nblk * d < (1LL << 40) && nblk < (1LL << 23)) ? ((1ULL << 40) / (unsigned long long)d + 1ULL) : 0ULL;
     };
     k.m_per_img = magic(k.per_img); k.m_ctiles = magic(k.ctiles); k.m_tiles_x = magic(k.tiles_x);
-    hipLaunchKernelGGL(conv3x3_s2_halo_kernel, dim3((unsigned)nblk), dim3(NT), SMEM, s, k);
+    if (a.f16) hipLaunchKernelGGL(conv3x3_s2_halo_kernel<true>, dim3((unsigned)nblk), dim3(NT), SMEM, s, k);
+    else hipLaunchKernelGGL(conv3x3_s2_halo_kernel<false>, dim3((unsigned)nblk), dim3(NT), SMEM, s, k);
     return hipGetLastError();
 }

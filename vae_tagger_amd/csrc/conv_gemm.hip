@@ -33,8 +33,10 @@ constexpr int ROWB = 128;         // bytes per LDS row = one K-step of a row: 64
 // F8: both operands are OCP e4m3 bytes (a.X / a.W reinterpreted; every "element" offset is then a byte offset) and a K-step is
 // ONE v_mfma_scale_f32_16x16x128_f8f6f4 per tile pair (both scales 2^0) instead of two v_mfma_f32_16x16x32_bf16: the same LDS and
 // DMA bytes per K-step carry twice the K, which is what a fill-bound tile needs (the stride-2 convs of the fp8 mode, flag 11).
-template <int BP, int BC, int WP, int WC, bool F8 = false>
+// F16: the 16-bit operands hold fp16 bits (v_mfma_f32_16x16x32_f16): conv_out in the fp16-operand mode of the convs (vt_set_flag 18).
+template <int BP, int BC, int WP, int WC, bool F8 = false, bool F16 = false>
 __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem, int logical) {
+    static_assert(!(F8 && F16), "one operand type");
     static_assert(WP * WC == 8, "8 waves per workgroup");
     constexpr int ES = F8 ? 1 : 2;            // bytes per element
     constexpr int BK = ROWB / ES;             // k-values per K-step
@@ -192,8 +194,14 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
-                    for (int j = 0; j < TP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TP; ++j) {
+                        if constexpr (F16) {
+                            typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8m, wf[i]), __builtin_bit_cast(f16x8m, xf[j]), acc[i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                        }
+                    }
             }
         }
     }
@@ -369,10 +377,10 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmArgs& a, char* smem
     }
 }
 
-template <int BP, int BC, int WP, int WC, bool OCC2 = false, bool F8 = false>
+template <int BP, int BC, int WP, int WC, bool OCC2 = false, bool F8 = false, bool F16 = false>
 __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_kernel(const ConvGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv_gemm_tile<BP, BC, WP, WC, F8>(a, smem, vt_xcd_remap(blockIdx.x, gridDim.x));
+    conv_gemm_tile<BP, BC, WP, WC, F8, F16>(a, smem, vt_xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Gated launches (a.gate: usually a no-op decided on the device) run as a small resident grid that walks the tiles, so a
@@ -387,12 +395,12 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void conv_gemm_gated_kernel(cons
     }
 }
 
-// fp8 launches (a.f8): plain grid only (no gated variant)
-template <int BP, int BC, int WP, int WC, bool OCC2 = false>
+// fp8 launches (a.f8) and fp16-operand launches (a.f16): plain grid only (no gated variant)
+template <int BP, int BC, int WP, int WC, bool OCC2 = false, bool F16 = false>
 hipError_t launch_cfg_f8(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BP + BC) * ROWB;
     static std::atomic<unsigned long long> attr_done{0};
-    auto kern = conv_gemm_kernel<BP, BC, WP, WC, OCC2, true>;
+    auto kern = conv_gemm_kernel<BP, BC, WP, WC, OCC2, !F16, F16>;
     hipError_t ea = vt_once_per_device(attr_done, [&] { return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
     if (ea != hipSuccess) return ea;
     const int HWo = a.Hout * a.Wout;
@@ -451,6 +459,10 @@ hipError_t vt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
     // per-image offsets are 32-bit
     if ((long long)a.Hin * a.Win * a.ldx >= (1LL << 31)) return hipErrorInvalidValue;
     if ((long long)a.Wrows * a.ldw >= (1LL << 31)) return hipErrorInvalidValue;
+    if (a.f16) {
+        if (a.f8 || a.gate || a.row_mode || vt_conv_gemm_config(a) != 0) return hipErrorInvalidValue;      // only conv_out's tile is instantiated
+        return launch_cfg_f8<128, 32, 8, 1, false, true>(a, s);
+    }
     if (a.f8) {
         switch (vt_conv_gemm_config(a)) {
             case 9: return launch_cfg_f8<192, 128, 4, 2, true>(a, s);

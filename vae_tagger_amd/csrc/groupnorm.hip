@@ -204,16 +204,18 @@ __global__ __launch_bounds__(FIN_T) void gn_finalize_kernel(const float* __restr
     }
 }
 
-// OUT8: the output is e4m3(out_scale * y), saturated at +-448 (1 B per element: the operand of the fp8 conv), else bf16.
+// OUT: 0 = bf16 rows; 1 = e4m3(out_scale * y), saturated at +-448 (1 B per element: the operand of the fp8 conv); 2 = fp16 rows (the
+// fp16-operand mode of the convs, vt_set_flag 18: 11 significand bits instead of bf16's 8 at the same 2 B).
 // A lane handles 8 consecutive channels of a pixel and stores 8 B of e4m3 (measured on MI355X at 16 x 1024^2: 4.7 TB/s of read +
 // write; 16 channels per lane with 16-B stores 3.8 TB/s; lane pairs exchanging through DPP so that half the lanes, or -- with two
 // pixels per lane -- all lanes store 16 B: 4.4 TB/s and 1 % slower end to end; plain instead of nontemporal stores -0.5 %).
-template <typename T, bool SILU, bool OUT8>
+template <typename T, bool SILU, int OUT>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x,
                                                               const float* __restrict__ scale_shift,
                                                               void* __restrict__ yv, int HW, int C,
                                                               int pix_per_block, float out_scale, int* __restrict__ status) {
     constexpr int CPL = 8;
+    constexpr bool OUT8 = OUT == 1;
     const int b = blockIdx.y;
     const int tpp = C / CPL, ppp = GN_THREADS / tpp;
     const int tc = threadIdx.x % tpp, tp = threadIdx.x / tpp;
@@ -259,6 +261,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
 #else
             __builtin_nontemporal_store(i32x2{o0, o1}, (i32x2*)((unsigned char*)yv + base + (long long)p * C));
 #endif
+        } else if constexpr (OUT == 2) {
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            f16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (f16_t)t[i];
+            __builtin_nontemporal_store(o, (f16x8*)((f16_t*)yv + base + (long long)p * C));
         } else {
             bf16x8 o;
 #pragma unroll
@@ -324,9 +332,10 @@ hipError_t vt_launch_gn_finalize(const float* partial, int nparts, int B, int C,
 }
 
 hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shift, void* y, int B, int HW,
-                              int C, int silu, hipStream_t s, float out_fp8_scale, int* status) {
+                              int C, int silu, hipStream_t s, float out_fp8_scale, int* status, int out_f16) {
     if (C % 8 || (GN_THREADS % (C / 8)) != 0 || C / 8 > GN_THREADS || B <= 0 || HW <= 0) return hipErrorInvalidValue;
     const bool o8 = out_fp8_scale > 0.f;
+    if (o8 && out_f16) return hipErrorInvalidValue;
     const int ppp = GN_THREADS / (C / 8);
 #ifndef GN_PASSES
 #define GN_PASSES 4
@@ -334,8 +343,8 @@ hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shi
     const int ppb = ppp * (out_fp8_scale > 0.f ? 2 * GN_PASSES : GN_PASSES);   // pixels per block: short blocks stream faster (bf16: 5.3 -> 5.9 TB/s at 4 passes; fp8 output: 8 passes +0.6 % images/s)
     dim3 grid((HW + ppb - 1) / ppb, B), block(GN_THREADS);
 #define GN_APPLY(T, A, O) hipLaunchKernelGGL((gn_apply_kernel<T, A, O>), grid, block, 0, s, (const T*)x, scale_shift, y, HW, C, ppb, out_fp8_scale, status)
-#define GN_APPLY2(T) do { if (silu) { if (o8) GN_APPLY(T, true, true); else GN_APPLY(T, true, false); } \
-                          else { if (o8) GN_APPLY(T, false, true); else GN_APPLY(T, false, false); } } while (0)
+#define GN_APPLY2(T) do { if (silu) { if (o8) GN_APPLY(T, true, 1); else if (out_f16) GN_APPLY(T, true, 2); else GN_APPLY(T, true, 0); } \
+                          else { if (o8) GN_APPLY(T, false, 1); else if (out_f16) GN_APPLY(T, false, 2); else GN_APPLY(T, false, 0); } } while (0)
     if (x_dtype == 1) GN_APPLY2(float);
     else if (x_dtype == 2) GN_APPLY2(f16_t);
     else GN_APPLY2(bf16_t);

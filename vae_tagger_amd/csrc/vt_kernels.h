@@ -39,6 +39,7 @@ struct ConvGemmArgs {
     int gate_expect;
     int x_stream;           // 1 = X is read once (P of P.V): its LDS-DMA carries the streaming (nt) cache policy
     int f8;                 // 1 = X and W are e4m3 bytes (ld* / *_bs in elements = bytes); fp8 MFMA, twice the K per K-step
+    int f16;                // 1 = X and W hold fp16 bits instead of bf16 (Cout <= 32 tile only: conv_out in the fp16-operand mode, vt_set_flag 18)
     const float* col_scale; // optional per-cout multiplier of the accumulator (before the bias)
     int short_tiles;        // 1 = short-K launches and the 128-cout stride-2 conv use the two-workgroups-per-CU tile (vt_set_flag 6)
 };
@@ -182,6 +183,8 @@ struct Conv3x3Args {
     const bf16_t* scW;      // packed [scCin/32][Cout][32] bf16, rows in the interleaved cout order
     int scCin;
     int occ2;               // two-workgroups-per-CU tile mode 0..3 (vt_set_flag 3; see conv3x3_halo.hip)
+    int f16;                // 1 = X, Wp, scX, scW hold fp16 bits (v_mfma_f32_16x16x32_f16): the fp16-operand mode, vt_set_flag 18
+    int out16_f16;          // 1 = out_bf16 receives fp16 bits (its consumer is a conv in that mode)
     // filled by the launcher: tile-grid constants of the chosen variant and their division multipliers (0 = divide)
     int tiles_x, ctiles, per_img, ptiles;
     unsigned long long m_per_img, m_ctiles, m_tiles_x;
@@ -192,6 +195,7 @@ int vt_conv3x3_halo_tiles_max(int H, int W);       // upper bound over the varia
 int vt_conv_gemm_ptiles(int HWo, int Cout);        // upper bound over configurations (buffer sizing)
 int vt_conv_gemm_ptiles_of(const ConvGemmArgs& a);  // of this launch (GroupNorm partials per image its epilogue writes)
 bool vt_conv3x3_halo_supported(int Cin, int Cout);
+bool vt_conv3x3_halo_f16_supported(int Cout, int occ2, int has_sc);
 int vt_conv3x3_halo_config(const Conv3x3Args& a);
 hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s);
 hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w_ohwi, bf16_t* wp, int Cin, int Cout, hipStream_t s);
@@ -206,6 +210,7 @@ struct Conv3x3S2Args {
     const void* zeros;
     float* gn_partial; int gn_cpg;                         // optional [batch][tiles][Cout/gn_cpg][3]
     int batch, H, W, Cin, Cout;
+    int f16, out16_f16;                                    // 1 = X and Wp hold fp16 bits (vt_set_flag 18) / out_bf16 receives fp16 bits
     int Ho, Wo, tiles_x, ctiles, per_img, ptiles;          // filled by the launcher
     unsigned long long m_per_img, m_ctiles, m_tiles_x;
 };
@@ -281,7 +286,8 @@ int vt_gn_max_chunks(int HW, int C);
 // y = act(x*scale + shift) -> bf16 rows, or (out_fp8_scale > 0) e4m3 rows of out_fp8_scale * y, saturated at +-448
 hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shift, void* y, int B, int HW,
                               int C, int silu, hipStream_t s, float out_fp8_scale = 0.f,
-                              int* status = nullptr /* e4m3 output: bit 1 of this device word is raised if a value was clamped */);
+                              int* status = nullptr /* e4m3 output: bit 1 of this device word is raised if a value was clamped */,
+                              int out_f16 = 0 /* 1: y is written as fp16 rows instead of bf16 (the convs' fp16-operand mode) */);
 
 hipError_t vt_launch_preprocess_u8(const unsigned char* in_hwc, float* out_nchw, int B, int H, int W, hipStream_t s);
 // Pillow's two-pass 8-bit resample; tab_*: [n_out][2 + ksize] int32 (first, count, 22-bit coefficients) on the device;

@@ -102,6 +102,11 @@ class EncodeTagPipeline:
         """BASELINE configs[4]: the 3x3 convs of the resnet / downsample stack on fp8 (e4m3) operands (vt_set_flag 11); tagging only."""
         self.ctx.call("vt_set_flag", 11, 1 if on else 0)
 
+    def set_fp16_operands(self, on=True):
+        """fp16 instead of bf16 MFMA operands for the convolutions (vt_set_flag 18): same bytes, 11 significand bits instead of 8 -- latents
+        ~6x closer to the fp32 reference, about 4 % fewer images/s (the matrix pipe draws more power on fp16 data).  Not in fp8 mode."""
+        self.ctx.call("vt_set_flag", 18, 1 if on else 0)
+
     def set_fp32_residual(self, on=True):
         """Store the residual stream as fp32 (and conv1 outputs as bf16) instead of fp16: for checkpoints whose activations
         exceed +-65504 (about 7 % slower)."""
