@@ -171,6 +171,11 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         (|x| <= 65504: GroupNorm + SiLU outputs and weights do; an overflow shows as status bit 0).  Ignored in fp8 mode (flag 11);
  *         needs the default kernel selection (flags 0, 2, 3, 13 at their defaults), other settings keep bf16 for the convs they affect.
  *         The attention keeps bf16 (its softmax numerators need bf16's range).  0 (default) = bf16 operands, BASELINE.json's dtype.
+ * flag 19: 1 (default) = the 16-bit (fp8 mode: e4m3) copy of a stage's output that feeds its stride-2 conv is written chunk-planar --
+ *         [C/32][H][W][32] (e4m3: [C/64][H][W][64]) per image instead of NHWC -- when a phase-plane kernel (flag 13) reads it: a 128-B line
+ *         then holds one channel chunk of two neighbouring pixels, the halves of a row's two planes staged three K-steps apart, instead of
+ *         two chunks of one pixel staged nine K-steps apart, by when the line has left the L2 (every line was fetched twice);
+ *         0 = NHWC.  Same arithmetic, same bits.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

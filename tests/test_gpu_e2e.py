@@ -946,3 +946,31 @@ def test_fp16_operand_mode_on_a_config_without_halo_tiles():
         ctx.call("vt_set_flag", 8, 1)
         ctx.call("vt_set_flag", 13, 1)
         m.set_fp16_operands(False)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp8", "fp16_operands"])
+def test_planar_downsample_input_is_bit_identical(vae, mode):
+    """vt_set_flag(ctx, 19, v): the copy of a stage's output that feeds its stride-2 conv, written chunk-planar ([C/32][H][W][32]; e4m3:
+    [C/64][H][W][64]) by the producing conv2 and gathered from there by the phase-plane kernel (default), against NHWC (0): the same values in
+    another place -- latents identical bit for bit in every numeric mode, on even, odd and ragged sizes."""
+    ctx = vae.vae._context()
+    old_check = vae.check_finite
+    vae.check_finite = False
+    try:
+        if mode == "fp8":
+            ctx.call("vt_set_flag", 11, 1)
+        if mode == "fp16_operands":
+            ctx.call("vt_set_flag", 18, 1)
+        for (b, hh, ww) in ((2, 128, 192), (1, 100, 76), (2, 72, 88), (1, 264, 136)):
+            x = synth.synth_images(b, hh, ww, seed=hh + ww).cuda()
+            ctx.call("vt_set_flag", 19, 1)
+            a = vae.encode(x)
+            ctx.call("vt_set_flag", 19, 0)
+            bb = vae.encode(x)
+            assert torch.isfinite(a).all() and torch.equal(a, bb), (mode, hh, ww, (a - bb).abs().max().item())
+        assert ctx.status() == 0
+    finally:
+        ctx.call("vt_set_flag", 19, 1)
+        ctx.call("vt_set_flag", 11, 0)
+        ctx.call("vt_set_flag", 18, 0)
+        vae.check_finite = old_check

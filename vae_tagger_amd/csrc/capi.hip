@@ -156,6 +156,8 @@ struct vt_context {
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
     int proj_fp8 = 1;               // vt_set_flag(ctx, 15, v): with the fp8 attention, the q | k and v projections on e4m3 operands too, writing q8 | k8 and v8^T directly
     int attn_fp8 = 1;               // vt_set_flag(ctx, 14, v): in fp8 mode (flag 11) Q.K^T and P.V run on e4m3 operands too (attn_fp8.hip)
+    int s2_planar = 1;              // vt_set_flag(ctx, 19, v): the 16-bit / e4m3 copy of a stage's output that feeds its stride-2 conv is written chunk-planar
+                                    // ([C/32 or C/64][H][W][chunk]) so that both halves of every 128-B line are staged three K-steps apart, not nine
     int f16_ops = 0;                // vt_set_flag(ctx, 18, v): fp16 instead of bf16 operands for the convs (same 2 B, 11 significand bits instead of 8)
     int attn_proj_kernel = 1;       // vt_set_flag(ctx, 17, v): the bf16 q | k and v^T projections on attn_qk.hip's skeleton (mode 4) instead of the generic GEMM
     int fp8_tile = 0;               // vt_set_flag(ctx, 16, v): fp8 halo conv tile shape = v & 3 (0: 8 x 32 px, 4 waves, two workgroups per CU; 1: 16 x 32 px;
@@ -505,12 +507,15 @@ bool conv_f16(const vt_context* c, const ConvW& w, int stride, bool has_sc) {
 // fused into the halo staging (only valid when norm_conv_fusable()).
 // `res` / `oh` are the residual-stream tensors (input to add, output to write): fp32 when rdt == 1, fp16 when rdt == 2.
 // `sc`: a 1x1 conv of sc->x fused into the halo launch (resnet conv_shortcut); then `res` must be null.
-struct ScFuse { const bf16_t* x; const bf16_t* wp; const float* bias; int cin; const bf16_t* wp8; const bf16_t* wp16; };
+struct ScFuse { const bf16_t* x; const bf16_t* wp; const float* bias; int cin; const bf16_t* wp8; const bf16_t* wp16;
+                bool x_f16;      // x carries fp16 bits (its producer wrote them for an fp16-operand conv2); else bf16
+};
 int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int Win, int stride, int pad, int Hout,
              int Wout, const void* res, void* oh, bf16_t* o16, hipStream_t s, GnState* gn = nullptr, int groups = 32,
              const float* xnorm_f32 = nullptr, const float* ss = nullptr, int rdt = 1, const ScFuse* sc = nullptr,
              bool x_fp8 = false, bool o16_e4m3 = false, bool x_f16 = false /* x (and sc->x) hold fp16 bits: conv_f16() of this conv */,
-             bool o16_f16 = false /* o16 is written as fp16 bits: conv_f16() of ITS consumer */) {
+             bool o16_f16 = false /* o16 is written as fp16 bits: conv_f16() of ITS consumer */,
+             bool planar = false /* stride 1: o16 is written chunk-planar; stride 2: x is chunk-planar (both: s2_input_planar() of the stride-2 conv) */) {
     const float* res32 = rdt == 1 ? (const float*)res : nullptr;
     const f16_t* res16 = rdt == 2 ? (const f16_t*)res : nullptr;
     float* o32 = rdt == 1 ? (float*)oh : nullptr;
@@ -525,7 +530,7 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
             Conv3x3S2Fp8Args h{};
             h.X = (const unsigned char*)x; h.Wp = w.wp8s2; h.mult = w.mult8g; h.bias = w.b; h.res = res32;
             h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
-            h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
+            h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout; h.x_planar = planar;
             if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_s2_fp8_tiles(Hout, Wout); }
             if (c->profiling) {
                 vt_context::ProfRec r;
@@ -573,7 +578,8 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
         Conv3x3Fp8Args h{};
         h.X = (const unsigned char*)x; h.Wp = w.wp8; h.mult = w.mult8; h.bias = w.b; h.res = res32; h.res_f16 = res16;
         h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16_e4m3 ? nullptr : o16; h.zeros = c->zeros;
-        if (o16_e4m3) { h.out_e4m3 = (unsigned char*)o16; h.out_e4m3_scale = FP8_RES_SCALE; h.status = c->status; }
+        if (o16_e4m3) { h.out_e4m3 = (unsigned char*)o16; h.out_e4m3_scale = FP8_RES_SCALE; h.status = c->status; h.out8_planar = planar; }
+        else if (planar) return c->fail(VT_ERR_STATE, "internal: planar bf16 copy requested from the fp8 conv");
         h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout;
         if (sc) { h.scX = sc->x; h.scW = sc->wp8; h.scCin = sc->cin; h.bias = sc->bias; }
         h.shape = (w.cin <= 128 || (c->fp8_tile & 4)) ? (c->fp8_tile & 3) : 0;
@@ -584,7 +590,7 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
     if (c->s2_halo && w.wp2 && w.k == 3 && stride == 2 && pad == 0 && Hout == Hin / 2 && Wout == Win / 2 && !res16 && !ss && !sc && !xnorm_f32) {
         Conv3x3S2Args h{};
         h.X = x; h.Wp = x_f16 ? w.wp2_16 : w.wp2; h.bias = w.b; h.res = res32; h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
-        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout; h.f16 = x_f16; h.out16_f16 = o16_f16;
+        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout; h.f16 = x_f16; h.out16_f16 = o16_f16; h.x_planar = planar;
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_s2_tiles(Hout, Wout); }
         if (c->profiling) {
             vt_context::ProfRec r;
@@ -605,14 +611,14 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
         Conv3x3Args h{};
         h.X = xnorm_f32 ? nullptr : x; h.Xf32 = xnorm_f32; h.scale_shift = ss;
         h.Wp = x_f16 ? w.wp16 : w.wp; h.bias = w.b; h.res = res32; h.res_f16 = res16; h.out_f32 = o32; h.out_f16 = oh16; h.out_bf16 = o16; h.zeros = c->zeros;
-        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout; h.f16 = x_f16; h.out16_f16 = o16_f16;
+        h.batch = B; h.H = Hin; h.W = Win; h.Cin = w.cin; h.Cout = w.cout; h.f16 = x_f16; h.out16_f16 = o16_f16; h.out16_planar = planar;
         if (sc) { h.scX = sc->x; h.scW = x_f16 ? sc->wp16 : sc->wp; h.scCin = sc->cin; h.bias = sc->bias; }
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout, ss ? (xnorm_f32 ? 1 : 2) : 0, c->halo_occ2, sc != nullptr); }
         HIPCK(c, launch_halo(c, h, s), "conv3x3_halo");
         return VT_OK;
     }
     if (ss || sc) return c->fail(VT_ERR_STATE, "internal: fused norm / shortcut requested for a conv the halo kernel cannot run");
-    if (x_f16 || o16_f16) return c->fail(VT_ERR_STATE, "internal: fp16 operands requested for a conv on the generic GEMM");
+    if (x_f16 || o16_f16 || planar) return c->fail(VT_ERR_STATE, "internal: fp16 operands / a planar layout requested for a conv on the generic GEMM");
     ConvGemmArgs a{};
     a.X = x; a.W = w.w; a.bias = w.b; a.res = res32; a.res_f16 = res16; a.out_f32 = o32; a.out_f16 = oh16; a.out_bf16 = o16; a.zeros = c->zeros;
     a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cin = w.cin; a.Cout = w.cout; a.Wrows = w.cout;
@@ -638,15 +644,18 @@ bool norm_conv_fusable(const vt_context* c, const ConvW& w, int cin) {
 // x: the tensor to normalise (xdt 0 = bf16 conv output, 1 = fp32 / 2 = fp16 residual stream); res / oh: residual in / out (rdt).
 int run_norm_conv(vt_context* c, const NormW& n, const ConvW& w, const void* x, int xdt, int B, int H, int W,
                   int groups, bf16_t* act, const void* res, void* oh, bf16_t* o16, GnState& gn, bool want_stats,
-                  hipStream_t s, int rdt, const ScFuse* sc = nullptr, bool o16_e4m3 = false, bool o16_f16 = false) {
+                  hipStream_t s, int rdt, const ScFuse* sc = nullptr, bool o16_e4m3 = false, bool o16_f16 = false, bool o16_planar = false) {
     const bool f8 = c->fp8 && w.wp8 && w.k == 3 && (!sc || sc->wp8);      // fp8 operands: the GroupNorm-apply pass writes e4m3, the conv reads it
     if (o16_e4m3 && !f8) return c->fail(VT_ERR_STATE, "internal: e4m3 output requested from a bf16 conv");
     if (f8 || xdt == 2 || !norm_conv_fusable(c, w, n.c)) {   // (the fused staging reads fp32 or bf16 only)
-        const bool h16 = !f8 && conv_f16(c, w, 1, sc != nullptr);             // fp16-operand mode: the pass writes fp16, the conv multiplies fp16
+        // fp16-operand mode: the pass writes fp16, the conv multiplies fp16 -- a fused shortcut's input must then carry fp16 bits too
+        const bool h16 = !f8 && conv_f16(c, w, 1, sc != nullptr) && (!sc || sc->x_f16);
+        if (sc && sc->x_f16 && !h16) return c->fail(VT_ERR_STATE, "internal: fp16 shortcut input for a bf16 conv");
         int r = run_gn(c, x, xdt, B, H * W, n, groups, 1, act, gn, s, f8, h16);
         if (r) return r;
-        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt, sc, f8, o16_e4m3, h16, o16_f16);
+        return run_conv(c, w, act, B, H, W, 1, 1, H, W, res, oh, o16, s, want_stats ? &gn : nullptr, groups, nullptr, nullptr, rdt, sc, f8, o16_e4m3, h16, o16_f16, o16_planar);
     }
+    if (o16_planar) return c->fail(VT_ERR_STATE, "internal: planar copy requested from the fused-norm staging path");
     if (sc) return c->fail(VT_ERR_STATE, "internal: fused shortcut with the fused-norm staging");
     int parts = gn.parts;
     if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, xdt, B, H * W, n.c, groups, gn.partial, &parts, s), "gn_stats");
@@ -1301,16 +1310,18 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
         gn.parts = fuse0 ? parts : 0;
     }
 
+    const bf16_t* h16 = nullptr;                   // 16-bit copy of the current h, when one exists ...
+    bool h16_is_f16 = false;                       // ... holding fp16 bits (fp16-operand mode, for a fused shortcut) instead of bf16
     auto fuse_sc = [&](const ResnetW& rw) {
         return c->fuse_shortcut && rw.sc_wp && c->use_halo_conv && rw.c2.wp && !c->fuse_gn_apply && (!(c->fp8 && rw.c2.wp8) || rw.sc_wp8);
     };
     // one ResnetBlock2D: h <- conv2(silu(gn(conv1(silu(gn(h)))))) + shortcut(h)
     // hb_e4m3: the stage's downsample conv runs on fp8 operands, so the block output for it is written as e4m3 instead of bf16
-    auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out, bool hb_e4m3 = false, bool hb_f16 = false) -> int {
+    auto resnet = [&](const ResnetW& rw, const bf16_t* h16_for_shortcut, bool want_bf16_out, bool hb_e4m3 = false, bool hb_f16 = false, bool hb_planar = false) -> int {
         const int nxt = (cur + 1) % 3, scb = (cur + 2) % 3;
         const void* res = f32[cur];
         int rr;
-        ScFuse scf{h16_for_shortcut, rw.sc_wp, rw.b_c2sc, rw.cin, rw.sc_wp8, rw.sc_wp16};
+        ScFuse scf{h16_for_shortcut, rw.sc_wp, rw.b_c2sc, rw.cin, rw.sc_wp8, rw.sc_wp16, h16_is_f16};
         const ScFuse* sc = nullptr;
         if (rw.has_sc) {
             if (fuse_sc(rw)) {
@@ -1330,15 +1341,14 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
                                 c1h ? nullptr : tmid, gn, true, s, rdt))) return rr;
         if (want_bf16_out) {
             // the only consumer is the downsample conv (bf16 operand, no norm): skip the fp32 copy of h and the stats
-            return run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt, sc, hb_e4m3, hb_f16);
+            return run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, nullptr, hb, gn, false, s, rdt, sc, hb_e4m3, hb_f16, hb_planar);
         }
         if ((rr = run_norm_conv(c, rw.n2, rw.c2, tmid, c1dt, B, h, w, e.groups, act, res, f32[nxt], nullptr, gn, true, s, rdt, sc))) return rr;
         cur = nxt;
         return VT_OK;
     };
 
-    const bf16_t* h16 = nullptr;                   // bf16 copy of the current h, when one exists
-    bool hb_is_e4m3 = false, hb_is_f16 = false;
+    bool hb_is_e4m3 = false, hb_is_f16 = false, hb_is_planar = false;
     for (size_t i = 0; i < e.stages.size(); ++i) {
         const StageW& st = e.stages[i];
         for (size_t j = 0; j < st.res.size(); ++j) {
@@ -1348,10 +1358,13 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             const bool down8 = last && st.has_down && c->fp8 && st.down.w8g && st.res[j].c2.wp8 && !st.res[j].has_sc;
             // fp16-operand mode: the block output for the stride-2 conv carries fp16 bits when that conv multiplies fp16 (conv_f16)
             const bool down16 = last && st.has_down && !down8 && conv_f16(c, st.down, 2, false);
-            if ((r = resnet(st.res[j], h16, last && st.has_down, down8, down16))) return r;
-            if (last) hb_is_f16 = down16;
+            // the copy is chunk-planar when the stride-2 conv that reads it runs on a phase-plane kernel (and the producer is a halo kernel that can write it so)
+            const bool planar = last && st.has_down && c->s2_planar && c->s2_halo && !c->fuse_gn_apply &&
+                                (down8 ? st.down.wp8s2 != nullptr : (st.down.wp2 != nullptr && c->use_halo_conv && st.res[j].c2.wp && !(c->fp8 && st.res[j].c2.wp8)));
+            if ((r = resnet(st.res[j], h16, last && st.has_down, down8, down16, planar))) return r;
+            if (last) { hb_is_f16 = down16; hb_is_planar = planar; }
             if (last) hb_is_e4m3 = down8;
-            h16 = (last && st.has_down) ? hb : nullptr;
+            h16 = (last && st.has_down) ? hb : nullptr; h16_is_f16 = false;
         }
         if (st.has_down) {
             // Downsample2D(padding=0): F.pad(x,(0,1,0,1)) then conv3x3 stride 2 -> out = floor(in/2)
@@ -1363,10 +1376,12 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
             // third rotating buffer (the block's `scb`, free now that no shortcut tensor is written)
             bf16_t* copy = !next_has_sc ? nullptr : (fuse_sc(e.stages[i + 1].res[0]) ? (bf16_t*)f32[(nxt + 2) % 3] : tmid);
             // ... and the bf16 copy for the next block's FUSED shortcut carries fp16 bits when that block's conv2 does
-            const bool copy16 = copy && fuse_sc(e.stages[i + 1].res[0]) && conv_f16(c, e.stages[i + 1].res[0].c2, 1, true);
+            // (only the phase-plane kernel can write them; on the generic GEMM the copy stays bf16 and that conv2 keeps bf16 operands)
+            const bool copy16 = copy && fuse_sc(e.stages[i + 1].res[0]) && conv_f16(c, e.stages[i + 1].res[0].c2, 1, true) &&
+                                c->s2_halo && st.down.wp2 && !hb_is_e4m3;
             if ((r = run_conv(c, st.down, hb, B, h, w, 2, 0, ho, wo, nullptr, f32[nxt], copy, s, &gn, e.groups, nullptr, nullptr, rdt, nullptr, hb_is_e4m3,
-                              false, hb_is_f16, copy16))) return r;
-            h16 = copy;
+                              false, hb_is_f16, copy16, hb_is_planar))) return r;
+            h16 = copy; h16_is_f16 = copy16;
             cur = nxt; h = ho; w = wo;
         }
     }
@@ -1610,6 +1625,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 12) { c->attn_pv_kernel = value != 0; return VT_OK; }
     if (flag == 17) { c->attn_proj_kernel = value != 0; return VT_OK; }
     if (flag == 18) { c->f16_ops = value != 0; return VT_OK; }
+    if (flag == 19) { c->s2_planar = value != 0; return VT_OK; }
     if (flag == 13) { c->s2_halo = value != 0; return VT_OK; }
     if (flag == 14) { c->attn_fp8 = value != 0; return VT_OK; }
     if (flag == 15) { c->proj_fp8 = value != 0; return VT_OK; }

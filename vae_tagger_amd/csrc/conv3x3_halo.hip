@@ -678,6 +678,8 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             }
         }
         if (a.out_bf16) {
+            // a.out16_planar: the 16-bit copy is laid out [Cout/32][H][W][32] (chunk-planar) for the stride-2 phase-plane kernel that reads it
+            const long long o16 = a.out16_planar ? (((long long)(b * (a.Cout >> 5) + (cw >> 5)) * a.H + y) * a.W + x) * 32 + (cw & 31) : o;
 #pragma unroll
             for (int i = 0; i < TC; i += 2) {
                 if (a.out16_f16) {                             // the operand copy carries fp16 bits when its consumer runs on fp16 operands
@@ -685,7 +687,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
                     f16x8o h;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { h[r] = (f16_t)acc[i][j][r]; h[4 + r] = (f16_t)acc[i + 1][j][r]; }
-                    *(f16x8o*)((f16_t*)a.out_bf16 + o + 4 * i) = h;
+                    *(f16x8o*)((f16_t*)a.out_bf16 + o16 + 4 * i) = h;
                 } else {
                 bf16x8 h;
 #pragma unroll
@@ -693,7 +695,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
 #ifdef EPI_NOSTORE
                 asm volatile("" :: "v"(h));
 #else
-                *(bf16x8*)(a.out_bf16 + o + 4 * i) = h;
+                *(bf16x8*)(a.out_bf16 + o16 + 4 * i) = h;
 #endif
                 }
             }

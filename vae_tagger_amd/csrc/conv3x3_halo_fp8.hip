@@ -426,7 +426,9 @@ __global__ __launch_bounds__(64 * WP * WX * WC, 2) void conv3x3_halo_fp8_kernel(
                     o8[i] = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], o8[i], false);
                     o8[i] = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], o8[i], true);
                 }
-                *(i32x4*)(a.out_e4m3 + o) = o8;
+                // a.out8_planar: [Cout/64][H][W][64] (chunk-planar) for the fp8 stride-2 phase-plane kernel (see conv3x3_s2_halo.hip)
+                const long long o8a = a.out8_planar ? (((long long)(b * (a.Cout >> 6) + (cw >> 6)) * a.H + y) * a.W + x) * 64 + (cw & 63) : o;
+                *(i32x4*)(a.out_e4m3 + o8a) = o8;
             }
             if (a.out_bf16) {
 #pragma unroll

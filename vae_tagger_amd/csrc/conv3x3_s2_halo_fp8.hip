@@ -110,7 +110,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_s2_halo_fp8_kernel(const Conv3x
             const int hy = hr / PITCH, hx = hr - hy * PITCH;
             const int iy = 2 * (ty0 + hy) + PY, ix = 2 * (tx0 + hx) + PX;
             const int lch = (lane & 3) ^ swz(hr);
-            const void* src = (iy < a.H && ix < a.W) ? (const void*)(Xb + ((iy * a.W + ix) * a.Cin + chunk * 64 + lch * 16)) : a.zeros;
+            // (a.x_planar: chunk-planar [Cin/64][H][W][64] instead of NHWC -- see conv3x3_s2_halo.hip)
+            const int xoff = a.x_planar ? ((chunk * a.H + iy) * a.W + ix) * 64 + lch * 16 : (iy * a.W + ix) * a.Cin + chunk * 64 + lch * 16;
+            const void* src = (iy < a.H && ix < a.W) ? (const void*)(Xb + xoff) : a.zeros;
             __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(dst + row0 * HB), 16, 0, 0);
         }
     };

@@ -185,6 +185,7 @@ struct Conv3x3Args {
     int occ2;               // two-workgroups-per-CU tile mode 0..3 (vt_set_flag 3; see conv3x3_halo.hip)
     int f16;                // 1 = X, Wp, scX, scW hold fp16 bits (v_mfma_f32_16x16x32_f16): the fp16-operand mode, vt_set_flag 18
     int out16_f16;          // 1 = out_bf16 receives fp16 bits (its consumer is a conv in that mode)
+    int out16_planar;       // 1 = out_bf16 is laid out [Cout/32][H][W][32] per image (chunk-planar) for the stride-2 phase-plane kernel (x_planar)
     // filled by the launcher: tile-grid constants of the chosen variant and their division multipliers (0 = divide)
     int tiles_x, ctiles, per_img, ptiles;
     unsigned long long m_per_img, m_ctiles, m_tiles_x;
@@ -211,6 +212,7 @@ struct Conv3x3S2Args {
     float* gn_partial; int gn_cpg;                         // optional [batch][tiles][Cout/gn_cpg][3]
     int batch, H, W, Cin, Cout;
     int f16, out16_f16;                                    // 1 = X and Wp hold fp16 bits (vt_set_flag 18) / out_bf16 receives fp16 bits
+    int x_planar;                                          // 1 = X is chunk-planar [Cin/32][H][W][32] per image instead of NHWC (vt_set_flag 19)
     int Ho, Wo, tiles_x, ctiles, per_img, ptiles;          // filled by the launcher
     unsigned long long m_per_img, m_ctiles, m_tiles_x;
 };
@@ -230,6 +232,7 @@ struct Conv3x3S2Fp8Args {
     const void* zeros;
     float* gn_partial; int gn_cpg;
     int batch, H, W, Cin, Cout;
+    int x_planar;                                          // 1 = X is chunk-planar [Cin/64][H][W][64] per image instead of NHWC (vt_set_flag 19)
     int Ho, Wo, tiles_x, ctiles, per_img, ptiles;          // filled by the launcher
     unsigned long long m_per_img, m_ctiles, m_tiles_x;
 };
@@ -246,6 +249,7 @@ struct Conv3x3Fp8Args {
     const float* res; const f16_t* res_f16;               // optional residual (at most one)
     float* out_f32; bf16_t* out_bf16; f16_t* out_f16;     // at least one of these four
     unsigned char* out_e4m3; float out_e4m3_scale;        // e4m3(scale * out), saturated: the operand of a following fp8 conv
+    int out8_planar;                                       // 1 = out_e4m3 is laid out [Cout/64][H][W][64] per image (chunk-planar; the fp8 stride-2 kernel's x_planar)
     int* status;                                           // optional device word: bit 1 raised when an e4m3 output was clamped
     const void* zeros;
     float* gn_partial; int gn_cpg;                         // optional [batch][tiles][Cout/gn_cpg][3]
