@@ -134,16 +134,20 @@ def cpu_baseline(x0, tags, flops_target, budget_s=85.0):
 
 def pmc_traffic(kernel, batch, height, width, fp8=False):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (tools/profile_round.sh: separate
-    FETCH_SIZE and WRITE_SIZE passes; both in KB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).
+    FETCH_SIZE and WRITE_SIZE passes; both in KB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md -- round 4's
+    tools/fetch_probe.hip: the counter tallies 64 B per request, whole 128-B lines cross the fabric).
     Only valid for the workload the counters were collected on (batch 16 x 1024^2); None otherwise."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03",
-                        f"pmc_traffic_b16_1024_{'fp8' if fp8 else 'bf16'}.json")
-    if (batch, height, width) != (16, 1024, 1024) or not os.path.exists(path):
+    root = os.path.dirname(os.path.abspath(__file__))
+    if (batch, height, width) != (16, 1024, 1024):
         return None, None
-    want = kernel.replace(" ", "")
-    for name, c in json.load(open(path)).items():
-        if want in name.replace(" ", "") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    want = kernel.replace(" ", "").rstrip(">")              # (template arguments added since -- e.g. ", false>" -- must not break the match)
+    for rnd in ("r04", "r03"):
+        path = os.path.join(root, "profiles", rnd, f"pmc_traffic_b16_1024_{'fp8' if fp8 else 'bf16'}.json")
+        if not os.path.exists(path):
+            continue
+        for name, c in json.load(open(path)).items():
+            if want in name.replace(" ", "") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, root)
     return None, None
 
 
