@@ -455,7 +455,7 @@ def main():
     # configs[4] per GPU (fp8 mode, same batch) and configs[3] (bucketed batches); ~2 s of GPU time, headline keys untouched
     default_run = (world == 1 and not (a.fp8 or a.f16 or a.bucketed or a.encode_only or a.generic_conv or a.no_occ2 or a.flag)
                    and not a.no_also)
-    also_f8_logits = also_f8_idx = None
+    also_f8_logits = also_f8_idx = also_f16 = None
     if default_run:
         also = {}
         K2, W2 = 10, 2
@@ -523,6 +523,28 @@ def main():
             "hbm_pass": {k: hbm3[k] for k in ("achieved", "frac", "share_of_step")}}
         also["configs3_bucketed"].update(end_to_end(n3 / e3, f3, 0.0))
         bucket_cache.clear()
+        # the precision mode (vt_set_flag 18: fp16 instead of bf16 MFMA operands for the convolutions) on the headline batch: what it costs, and
+        # -- filled in by the parity block below -- what it buys on a SMOOTH picture, where bf16 operands leave north_star's 1e-2
+        pipe.set_fp16_operands(True)
+        try:
+            for _ in range(W2):
+                plain_step()
+            with power:
+                e16, out16, prof16 = timed([plain_step] * K2)
+            power16 = power.summary()
+            also_f16 = pipe.logits(x[:1], return_latent=True)
+            st16 = prof_ctx.status()
+        finally:
+            pipe.set_fp16_operands(False)
+        assert torch.isfinite(out16).all() and st16 == 0
+        roof16, hbm16, _ = roofline_of(prof16, e16)
+        ips16 = B * K2 / e16
+        also["precision_mode_fp16_operands"] = {
+            "workload": f"batch {B}/GPU {a.width}x{a.height} encode+tag, {a.tags} tags, fp16 instead of bf16 MFMA operands for every convolution (vt_set_flag 18; attention bf16)",
+            "value": round(ips16, 3), "unit": "images/sec", "steps": K2, "warmup": W2, "ms_per_step": round(e16 / K2 * 1e3, 3), "dtype": "f16",
+            "roofline": {k: roof16[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms")},
+            "joules_per_image": None if power16 is None else round(power16["socket_w_median"] / ips16, 3)}
+        also["precision_mode_fp16_operands"].update(end_to_end(ips16, fimg, 0.0))
         res["also"] = also
 
     if rank == 0:
@@ -555,6 +577,36 @@ def main():
             else:
                 par["latents_within_tolerance"] = bool(dlat <= tol)
             res["parity"] = par
+            if also_f16 is not None:
+                m16 = res["also"]["precision_mode_fp16_operands"]
+                m16["max_abs_dlogit"] = float(f"{(also_f16[0].cpu() - ref_lg).abs().max().item():.3e}")
+                m16["max_abs_dlatent"] = float(f"{(also_f16[1].cpu() - ref_lat).abs().max().item():.3e}")
+                # a smooth picture (a random 12 x 12 field upsampled bicubically + a little noise, clamped, 8 bits per channel like a decoded file),
+                # 512^2: the HIP path with bf16 and with fp16 operands against the fp32 oracle; the oracle with bf16-rounded operands beside them
+                import torch.nn.functional as F
+                from oracle import decoder_ref, encoder_ref
+                g = torch.Generator().manual_seed(7)
+                pic = F.interpolate(torch.rand(1, 3, 12, 12, generator=g), size=(512, 512), mode="bicubic", align_corners=False)
+                pic = ((pic + 0.06 * torch.randn(1, 3, 512, 512, generator=g)).clamp(0, 1) * 255).to(torch.uint8)
+                pic = (pic.float() / 255.0 - 0.5) / 0.5
+                sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+                with torch.no_grad():
+                    lat_ref = encoder_ref.vae_wrapper_encode(sd_e, pic)
+                    lat_emu = encoder_ref.vae_wrapper_encode(sd_e, pic, emulate_bf16=True)
+                lat_b = pipe.logits(pic.to(dev), return_latent=True)[1].cpu()
+                pipe.set_fp16_operands(True)
+                try:
+                    lat_h = pipe.logits(pic.to(dev), return_latent=True)[1].cpu()
+                finally:
+                    pipe.set_fp16_operands(False)
+                e3 = lambda t: float(f"{t:.3e}")
+                res["parity"]["smooth_picture_512"] = {
+                    "what": "max |dlatent| against the fp32 oracle on a smooth 512x512 picture (flat regions make neighbouring pixels' rounding errors equal: "
+                            "a 3x3 conv adds them coherently) -- bf16 operands leave north_star's 1e-2 there, in this path and in the oracle's own bf16 emulation",
+                    "hip_bf16_operands": e3((lat_b - lat_ref).abs().max().item()), "hip_fp16_operands": e3((lat_h - lat_ref).abs().max().item()),
+                    "oracle_with_bf16_rounded_operands": e3((lat_emu - lat_ref).abs().max().item()),
+                    "rms_hip_bf16_operands": e3((lat_b - lat_ref).pow(2).mean().sqrt().item()),
+                    "fp16_operands_within_tolerance": bool((lat_h - lat_ref).abs().max().item() <= tol)}
             if also_f8_logits is not None:
                 d8 = float(f"{(also_f8_logits.cpu() - ref_lg).abs().max().item():.3e}")
                 res["also"]["configs4_fp8_per_gpu"]["max_abs_dlogit"] = d8
