@@ -458,7 +458,7 @@ def test_small_config_with_fused_shortcut_on_every_halo_tile_mode():
     ref = encoder_ref.encoder_moments(sd, x, n_down=2)
     ctx = m._context()
     try:
-        for occ2 in (0, 1, 2, 3):
+        for occ2 in (0, 1, 2, 3, 4):                          # (4: the one-wave-per-SIMD experiment tile)
             for fuse_sc in (1, 0):
                 ctx.call("vt_set_flag", 3, occ2)
                 ctx.call("vt_set_flag", 8, fuse_sc)

@@ -92,7 +92,8 @@ def test_attention_lds_reads_are_ahead_of_their_mfmas(attention_asm, kernel):
 # the fp8 attention when an overflow watch was added).  The table is what the committed sources compile to; a spill that creeps in shows up here, on the
 # CPU, instead of as a few per cent on the GPU.
 _BUDGET = {  # file: {kernel substring: max vgpr_spill_count}
-    "conv3x3_halo": {"conv3x3_halo_kernelILi2ELi2ELi0ELi8ELi4ELb0E": 0, "conv3x3_halo_kernelILi2ELi2ELi0ELi8ELi4ELb1E": 0},      # bf16 / fp16 operands
+    "conv3x3_halo": {"conv3x3_halo_kernelILi2ELi2ELi0ELi8ELi4ELb0E": 0, "conv3x3_halo_kernelILi2ELi2ELi0ELi8ELi4ELb1E": 0,       # bf16 / fp16 operands
+                     "conv3x3_halo_kernelILi2ELi2ELi0ELi16ELi6ELb0E": 30},   # the one-wave-per-SIMD experiment tile: 256 AGPRs + 256 VGPRs, spills outside the loop
     "conv3x3_halo_fp8": {"conv3x3_halo_fp8_kernelILi2ELi1E": 0, "conv3x3_halo_fp8_kernelILi4ELi1E": 0, "conv3x3_halo_fp8_kernelILi2ELi2E": 0},
     "conv3x3_s2_halo": {"conv3x3_s2_halo_kernelILb0E": 3, "conv3x3_s2_halo_kernelILb1E": 3},            # three, in the last chunk's epilogue hand-over, none in the steady-state loop
     "conv3x3_s2_halo_fp8": {"conv3x3_s2_halo_fp8_kernel": 0},
@@ -122,5 +123,6 @@ def test_mfma_kernels_keep_two_waves_per_simd_without_spilling(budget_asm, name)
     kernels = {b["name"]: b for b in blocks if "name" in b and "vgpr_count" in b}
     for sub, max_spill in _BUDGET[name].items():
         (k, b), = [(k, b) for k, b in kernels.items() if sub in k]
-        assert int(b["vgpr_count"]) <= 256, (k, b["vgpr_count"])
+        one_wave = "ELi16ELi6E" in k                                # the one-wave-per-SIMD experiment tile: 256 VGPRs + 256 AGPRs by design
+        assert int(b["vgpr_count"]) <= (512 if one_wave else 256), (k, b["vgpr_count"])
         assert int(b["vgpr_spill_count"]) <= max_spill and int(b["sgpr_spill_count"]) == 0, (k, b["vgpr_spill_count"], b["sgpr_spill_count"])

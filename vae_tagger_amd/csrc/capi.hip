@@ -1613,7 +1613,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 0) { c->use_halo_conv = value != 0; return VT_OK; }
     if (flag == 1) { c->fuse_gn_stats = value != 0; return VT_OK; }
     if (flag == 2) { c->fuse_gn_apply = value != 0; return VT_OK; }
-    if (flag == 3) { c->halo_occ2 = value < 0 ? 0 : (value > 3 ? 3 : value); return VT_OK; }
+    if (flag == 3) { c->halo_occ2 = value < 0 ? 0 : (value > 4 ? 4 : value); return VT_OK; }
     if (flag == 4) { c->res_fp16 = value != 0; return VT_OK; }
     if (flag == 5) { c->conv_in_mfma = value != 0; return VT_OK; }
     if (flag == 6) { c->gemm_short = value != 0; return VT_OK; }

@@ -137,13 +137,14 @@ __device__ __forceinline__ void wait_vmcnt_tied1(int n, V& r0) {
 //   <4,2,0,4,4>  8 waves x 128 VGPRs, same tile, two workgroups per CU (the earlier form of the same idea);
 //   <2,4,.,8,6> / <4,2,.,8,6>  8 waves x 256 VGPRs, 256 / 128 couts, one workgroup per CU (and the only shapes of XT != 0).
 template <int WP, int WC, int XT, int TPW, int NW, bool F16 = false>
-__global__ __launch_bounds__(64 * WP * WC, TPW == 4 ? 4 : 2)
+__global__ __launch_bounds__(64 * WP * WC, TPW == 4 ? 4 : TPW == 16 ? 1 : 2)
 void conv3x3_halo_kernel(const Conv3x3Args a) {
     static_assert(!F16 || XT == 0, "fp16 operands: plain-input tiles only");
     constexpr int NWV = WP * WC;                 // waves per workgroup
     constexpr int NT = 64 * NWV;
-    static_assert((NWV == 8 && (TPW == 8 || (TPW == 4 && XT == 0))) || (NWV == 4 && TPW == 8 && XT == 0),
-                  "8 waves x 8 rows, 8 waves x 4 rows (two workgroups per CU), or 4 waves x 8 rows (two workgroups per CU)");
+    static_assert((NWV == 8 && (TPW == 8 || (TPW == 4 && XT == 0))) || (NWV == 4 && (TPW == 8 || TPW == 16) && XT == 0),
+                  "8 waves x 8 rows, 8 waves x 4 rows (two workgroups per CU), 4 waves x 8 rows (two workgroups per CU), or -- the round-4 "
+                  "experiment -- 4 waves x 16 rows: ONE wave per SIMD with up to 512 registers (accumulators in AGPRs)");
     constexpr int ROWS = WP * TPW;               // tile rows (each wave: TPW rows x 16 px)
     constexpr int BC = WC * 64;                  // couts per workgroup (each wave: 64)
     constexpr int TP = TPW, TC = 4;
@@ -367,7 +368,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     // group's row r as soon as its last reader has issued: row 0 after (dy 0, j 0), row 1 after (dy 1, j 0), row r >= 2
     // after (dy 2, j = r-2).  The 128-VGPR variant (TPW = 4) has no room for the two extra fragments: it keeps one
     // fragment per output row and re-reads it for every tap.
-    constexpr bool DYR = TPW == 8;
+    constexpr bool DYR = TPW >= 8;
     bf16x8 wfc[TC], xr[DYR ? TP + 2 : TP];
     STAMP(1);
     if constexpr (SPF) {
@@ -551,7 +552,7 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
     };
     for (int chunk = 0; chunk + 1 < nchunk; ++chunk) do_chunk(chunk, std::false_type{});
     do_chunk(nchunk - 1, std::true_type{});
-    if constexpr (XT == 0 && TPW == 8) {                 // (the 128-VGPR tile has no registers to spare: the launcher avoids it)
+    if constexpr (XT == 0 && TPW >= 8) {                 // (the 128-VGPR tile has no registers to spare: the launcher avoids it)
         if (a.scX) {
             // ---- fused 1x1 shortcut: acc += scW . scX at the centre tap, scCin / 32 plain (un-pipelined) K-steps.  A block
             // whose channel count changes used to pay a separate GEMM launch writing shortcut(x) and this epilogue reading
@@ -783,18 +784,19 @@ hipError_t vt_launch_repack_ohwi_to_halo(const bf16_t* w, bf16_t* wp, int Cin, i
 //   3 = mode 2 for EVERY plain-input layer (256-cout layers run two 128-cout tiles per pixel tile).
 // ONE function decides the kernel variant; the launcher, the profile slot and the GroupNorm-partials count all use it.
 namespace {
-enum HaloVariant { HV_2208_4 = 0, HV_4204_4, HV_4208_6, HV_2408_6, HV_XT1_128, HV_XT1_256, HV_XT2_128, HV_XT2_256 };
+enum HaloVariant { HV_2208_4 = 0, HV_4204_4, HV_4208_6, HV_2408_6, HV_XT1_128, HV_XT1_256, HV_XT2_128, HV_XT2_256, HV_2216_6 };
 HaloVariant halo_variant(int Cout, int xt, int occ2, bool has_sc) {
     const bool big = (Cout % 256) == 0;                     // 16x16 px x 256 couts, else 32x16 px x 128 couts
     if (xt == 1) return big ? HV_XT1_256 : HV_XT1_128;
     if (xt == 2) return big ? HV_XT2_256 : HV_XT2_128;
+    if (occ2 == 4) return HV_2216_6;                        // round-4 experiment: one wave per SIMD, 32 x 16 px x 128 couts per workgroup
     if (occ2 == 3 || (occ2 == 2 && !big)) return HV_2208_4;                     // 4 waves, 2 workgroups / CU
     if (occ2 && !big && !has_sc) return HV_4204_4;          // (the 128-VGPR tile has no registers for the fused shortcut)
     return big ? HV_2408_6 : HV_4208_6;
 }
 int halo_variant_rows(HaloVariant v) {
     switch (v) {
-        case HV_4208_6: case HV_XT1_128: case HV_XT2_128: return 32;
+        case HV_4208_6: case HV_XT1_128: case HV_XT2_128: case HV_2216_6: return 32;
         default: return 16;
     }
 }
@@ -818,6 +820,7 @@ int vt_conv3x3_halo_config(const Conv3x3Args& a) {      // profile slots 3..8
         case HV_4204_4: return 4;
         case HV_4208_6: return 5;
         case HV_2408_6: return 6;
+        case HV_2216_6: return 5;                           // (shares the one-workgroup-per-CU 128-cout slot)
         case HV_XT1_128: case HV_XT1_256: return 7;
         default: return 8;
     }
@@ -832,7 +835,7 @@ hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
     if ((a.scX != nullptr) != (a.scW != nullptr)) return hipErrorInvalidValue;
     if (a.scX && (a.scCin <= 0 || (a.scCin % 32) || a.scale_shift || (long long)a.H * a.W * a.scCin >= (1LL << 31))) return hipErrorInvalidValue;
     if ((long long)(a.Cin / 32) * 9 * a.Cout * 32 >= (1LL << 31)) return hipErrorInvalidValue;
-    if (a.occ2 < 0 || a.occ2 > 3) return hipErrorInvalidValue;
+    if (a.occ2 < 0 || a.occ2 > 4) return hipErrorInvalidValue;
     // input mode: raw bf16 (X), or GroupNorm+SiLU fused into the staging of an fp32 (Xf32) / bf16 (X) tensor
     const int xt = halo_xt(a);
     if (xt == 1 ? (a.X != nullptr) : (a.X == nullptr || a.Xf32 != nullptr)) return hipErrorInvalidValue;
@@ -843,6 +846,7 @@ hipError_t vt_launch_conv3x3_halo(const Conv3x3Args& a, hipStream_t s) {
         case HV_4204_4: return launch<4, 2, 0, 4, 4>(a, s);
         case HV_4208_6: return launch<4, 2, 0, 8>(a, s);
         case HV_2408_6: return launch<2, 4, 0, 8>(a, s);
+        case HV_2216_6: return launch<2, 2, 0, 16, 6>(a, s);
         case HV_XT1_128: return launch<4, 2, 1, 8>(a, s);
         case HV_XT1_256: return launch<2, 4, 1, 8>(a, s);
         case HV_XT2_128: return launch<4, 2, 2, 8>(a, s);

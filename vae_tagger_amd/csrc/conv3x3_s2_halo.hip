@@ -104,6 +104,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_s2_halo_kernel(const Conv3x3S2A
     const int ty0 = tyi * ROWS, tx0 = (tile - tyi * a.tiles_x) * TW;       // output coordinates
     const int c0 = ct * BC;
     const bf16_t* Xb = a.X + (long long)b * a.H * a.W * a.Cin;
+    const int xpix = a.x_planar ? 32 : a.Cin, xchunk = a.x_planar ? a.H * a.W * 32 : 32;      // element strides of a pixel / a 32-channel chunk (wave-uniform)
     const int nchunk = a.Cin >> 5;
     const int nk = nchunk * 9;
 
@@ -137,8 +138,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_s2_halo_kernel(const Conv3x3S2A
             // NHWC: pixel stride Cin; chunk-planar ([Cin/32][H][W][32], a.x_planar): a 128-B line holds the SAME chunk of two neighbouring pixels,
             // i.e. the two halves a row's px = 0 / px = 1 planes take three K-steps apart -- instead of two chunks of one pixel taken nine steps
             // apart, by when the line has left the L2 (rocprofv3: every line of X was fetched twice)
-            const int xoff = a.x_planar ? ((chunk * a.H + iy) * a.W + ix) * 32 + lch * 8 : (iy * a.W + ix) * a.Cin + chunk * 32 + lch * 8;
-            const void* src = (iy < a.H && ix < a.W) ? (const void*)(Xb + xoff) : a.zeros;
+            const void* src = (iy < a.H && ix < a.W) ? (const void*)(Xb + ((iy * a.W + ix) * xpix + chunk * xchunk + lch * 8)) : a.zeros;
             __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(dst + row0 * HB), 16, 0, 0);
         }
     };

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_s2_halo_fp8_kernel(const Conv3x
     const int ty0 = tyi * ROWS, tx0 = (tile - tyi * a.tiles_x) * TWX;       // output coordinates
     const int c0 = ct * BC;
     const unsigned char* Xb = a.X + (long long)b * a.H * a.W * a.Cin;
+    const int xpix = a.x_planar ? 64 : a.Cin, xchunk = a.x_planar ? a.H * a.W * 64 : 64;      // byte strides of a pixel / a 64-channel chunk (wave-uniform)
     const int nchunk = a.Cin >> 6;
 
     // ---- DMA bookkeeping: one wave-instruction = 16 LDS rows x 64 B; lane l -> row (l >> 2), physical chunk (l & 3),
@@ -111,8 +112,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_s2_halo_fp8_kernel(const Conv3x
             const int iy = 2 * (ty0 + hy) + PY, ix = 2 * (tx0 + hx) + PX;
             const int lch = (lane & 3) ^ swz(hr);
             // (a.x_planar: chunk-planar [Cin/64][H][W][64] instead of NHWC -- see conv3x3_s2_halo.hip)
-            const int xoff = a.x_planar ? ((chunk * a.H + iy) * a.W + ix) * 64 + lch * 16 : (iy * a.W + ix) * a.Cin + chunk * 64 + lch * 16;
-            const void* src = (iy < a.H && ix < a.W) ? (const void*)(Xb + xoff) : a.zeros;
+            const void* src = (iy < a.H && ix < a.W) ? (const void*)(Xb + ((iy * a.W + ix) * xpix + chunk * xchunk + lch * 16)) : a.zeros;
             __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(dst + row0 * HB), 16, 0, 0);
         }
     };
