@@ -275,3 +275,42 @@ def test_sharded_cli_two_ranks_rehearsal(tmp_path):
         got = json.loads((tmp_path / "two" / name).read_text())
         assert got == want
         assert "失败: 1" in r.stdout.decode()                         # the broken file is counted once, on the rank that owns it
+
+
+@pytest.mark.gpu
+def test_sharded_cli_collectives_run_on_rccl_with_one_rank(tmp_path):
+    """The sharded CLI path's three exchanges -- image-list broadcast, the fp8-abandoned all-reduce, the result gather -- on the REAL backend:
+    VT_CLI_ONE_RANK_GROUP=1 makes `infer_full` / `infer_vae` create a one-rank "nccl" (= RCCL) group before any GPU call and go through the
+    same collective calls a multi-GPU torchrun launch makes (this box has one GPU; a two-rank run has to use gloo).  Same JSON as the plain run.
+    It proves the calls execute on RCCL with CUDA-side object collectives; it says nothing about scaling."""
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    from safetensors.torch import save_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_tags, res = 40, 96
+    g = torch.Generator().manual_seed(9)
+    imgs = tmp_path / "imgs"
+    imgs.mkdir()
+    for i in range(5):
+        Image.fromarray((torch.rand(80 + 4 * i, 100, 3, generator=g) * 255).to(torch.uint8).numpy()).save(imgs / f"img{i}.png")
+    save_file(synth.synth_state_dict(synth.encoder_manifest(), seed=0), str(tmp_path / "vae.safetensors"))
+    torch.save(synth.synth_state_dict(synth.attention_decoder_manifest(n_tags), seed=1), tmp_path / "dec.pth")
+    (tmp_path / "tags.csv").write_text("name\n" + "\n".join(f"tag_{i:05d}" for i in range(n_tags)) + "\n")
+    common = ["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--image_path", str(imgs), "--resolution", str(res), "--batch_size", "2"]
+    full = common + ["--decoder_checkpoint", str(tmp_path / "dec.pth"), "--tags_csv_path", str(tmp_path / "tags.csv"), "--fp8"]
+    one = infer_full.main(full + ["--output_dir", str(tmp_path / "one")])
+    one_lat = infer_vae.main(common + ["--output_dir", str(tmp_path / "one")])
+    env = dict(os.environ, VT_CLI_ONE_RANK_GROUP="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29990 - os.getpid() % 40), PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    for mod, args, name, want in (("vae_tagger_amd.infer_full", full, "classification_results.json", one),
+                                  ("vae_tagger_amd.infer_vae", common, "latent_vectors.json", one_lat)):
+        probe = ("import sys, runpy, torch.distributed as dist\n"
+                 f"sys.argv = [{mod!r}] + {args + ['--output_dir', str(tmp_path / 'grp')]!r}\n"
+                 f"runpy.run_module({mod!r}, run_name='__main__')\n"
+                 "assert dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world_size() == 1\n"
+                 "print('GROUP_OK', dist.get_backend())\n")
+        r = subprocess.run([sys.executable, "-c", probe], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+        assert r.returncode == 0 and b"GROUP_OK nccl" in r.stdout, (r.stdout.decode()[-800:], r.stderr.decode()[-2000:])
+        assert json.loads((tmp_path / "grp" / name).read_text()) == want

@@ -131,9 +131,12 @@ def summarize_batch(pipe, conf, idx, tag_names, threshold, top_k=TOP_K):
 def _dist_setup():
     """(world, rank, device index).  Under torchrun (WORLD_SIZE > 1) the process group is created here, BEFORE any GPU call of this
     process: "nccl" (= RCCL) with one GPU per rank, "gloo" when the ranks have to share GPUs (a rehearsal on a one-GPU box,
-    VT_CLI_GLOO=1).  The image list is split by `sharding.shard_range`; the only exchange is a gather of the finished entries."""
+    VT_CLI_GLOO=1).  The image list is split by `sharding.shard_range`; the only exchange is a gather of the finished entries.
+    VT_CLI_ONE_RANK_GROUP=1 creates the (RCCL) group even for ONE rank, so that the object collectives of the sharded path -- list
+    broadcast, fp8-abandoned all-reduce, result gather -- execute on the real backend on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    one_rank_group = world <= 1 and os.environ.get("VT_CLI_ONE_RANK_GROUP") == "1"
+    if world <= 1 and not one_rank_group:
         return 1, 0, None
     import torch.distributed as dist
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -144,15 +147,21 @@ def _dist_setup():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not dist.is_initialized():
         if gloo:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", world_size=max(world, 1), rank=rank)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    return world, rank, local % ngpu
+            dist.init_process_group("nccl", world_size=max(world, 1), rank=rank, device_id=torch.device("cuda", local % ngpu))
+    return max(world, 1), rank, local % ngpu
+
+
+def _grouped():
+    """A process group exists (torchrun, or the one-rank rehearsal): the sharded path's collectives run."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 def gather_results(items, processed, errors, world, rank):
     """Rank 0 receives every rank's [(path, entry)] and counters (torch.distributed.gather_object); the others get (None, 0, 0)."""
-    if world == 1:
+    if world == 1 and not _grouped():
         return items, processed, errors
     import torch.distributed as dist
     objs = [None] * world if rank == 0 else None
@@ -299,7 +308,7 @@ def infer_and_classify(args):
     if not os.path.exists(args.image_path):
         raise FileNotFoundError(f"图像路径未找到: {args.image_path}")
     image_paths = get_image_paths(args.image_path)
-    if world > 1:
+    if _grouped():
         import torch.distributed as dist
         box = [image_paths]                              # the reference's order is a set's: every rank works from rank 0's list
         dist.broadcast_object_list(box, src=0)
@@ -361,7 +370,7 @@ def infer_and_classify(args):
     # ONE output file holds ONE numeric mode: if fp8 was abandoned anywhere (on any rank), the entries computed in fp8 mode are redone in bf16
     fp8_asked = bool(getattr(args, "fp8", False))
     abandoned = fp8_asked and not tg.fp8
-    if world > 1 and fp8_asked:
+    if _grouped() and fp8_asked:
         import torch.distributed as dist
         flag = torch.tensor([1 if abandoned else 0], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)

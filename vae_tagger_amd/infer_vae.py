@@ -61,7 +61,7 @@ class _EncoderInput:
 
 
 def infer_and_save_latents(args):
-    from .infer_full import _dist_setup, gather_results
+    from .infer_full import _dist_setup, _grouped, gather_results
     world, rank, dev_index = _dist_setup()
     if not torch.cuda.is_available():
         raise RuntimeError("vae_tagger_amd needs an MI355X (no HIP device visible; there is no CPU fallback)")
@@ -77,7 +77,7 @@ def infer_and_save_latents(args):
     if not os.path.exists(args.image_path):
         raise FileNotFoundError(f"图像路径未找到: {args.image_path}")
     image_paths = get_image_paths(args.image_path)
-    if world > 1:
+    if _grouped():
         import torch.distributed as dist
         box = [image_paths]
         dist.broadcast_object_list(box, src=0)
