@@ -156,6 +156,21 @@ def test_infer_full_and_infer_vae_end_to_end(tmp_path, monkeypatch):
     monkeypatch.setattr(EncodeTagPipeline, "status_async", real_async)
     monkeypatch.setattr(EncodeTagPipeline, "status", real_status)
     assert calls["n"] >= 2 and late == res_full
+    # --fp16_operands on a checkpoint whose first GroupNorm output leaves the fp16 range: the operands overflow, the next norm's statistics are
+    # not finite, the health word says so and the CLI settles on bf16 operands + fp32 residual storage -- where the default run of that checkpoint
+    # ends up too (its fp16-stored conv1 output overflows as well): the same file
+    sd_huge = dict(sd_e)
+    for k in ("weight", "bias"):
+        sd_huge[f"encoder.down_blocks.0.resnets.0.norm1.{k}"] = sd_e[f"encoder.down_blocks.0.resnets.0.norm1.{k}"] * 1.0e5
+    save_file(sd_huge, str(tmp_path / "vae_huge.safetensors"))
+    huge_default = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae_huge.safetensors"), "--output_dir", str(tmp_path / "out_h0")] + common)
+    huge_f16 = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae_huge.safetensors"), "--output_dir", str(tmp_path / "out_h1"), "--fp16_operands"] + common)
+    assert len(huge_default) == 3 and huge_f16 == huge_default
+    # the precision mode on the healthy checkpoint: same schema, confidences within 1e-3 of the default path's (logits move by ~3e-4)
+    res_f16 = infer_full.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--output_dir", str(tmp_path / "out_f16"), "--fp16_operands"] + common)
+    assert set(res_f16) == set(res_full)
+    for k in res_full:
+        assert abs(res_f16[k]["max_confidence"] - res_full[k]["max_confidence"]) <= 1e-3
     lat = infer_vae.main(["--vae_checkpoint", str(tmp_path / "vae.safetensors"), "--image_path", str(imgs),
                           "--output_dir", str(out), "--resolution", str(res)])
     assert len(lat) == 3 and all(len(v) == 16 * (res // 8) ** 2 for v in lat.values())

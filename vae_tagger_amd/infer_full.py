@@ -176,8 +176,9 @@ class _Tagger:
     """The device leg of the loop: one batch -> JSON entries, with the health word's fall-backs (fp16 -> fp32 residual storage, fp8 -> bf16) and the
     reference's error granularity (a failure costs ONE image: infer_full.py:130-132)."""
 
-    def __init__(self, pipe, tag_names, threshold, fp8):
+    def __init__(self, pipe, tag_names, threshold, fp8, f16=False):
         self.pipe, self.tag_names, self.thr = pipe, tag_names, threshold
+        self.f16 = bool(f16)            # fp16 instead of bf16 conv operands (vt_set_flag 18): values must fit fp16
         self.fp8 = bool(fp8)            # current numeric mode of the context
         self.fp32_res = False
         self.epoch = 0                  # bumped by every permanent mode switch: batches enqueued before it are redone
@@ -201,13 +202,14 @@ class _Tagger:
         if st:
             was_fp8, was_res = self.fp8, self.fp32_res
             if st & VT_STATUS_NONFINITE or (st & VT_STATUS_FP8_SATURATED and not was_fp8):
-                pipe.set_fp8(False); pipe.set_fp32_residual(True)
+                pipe.set_fp8(False); pipe.set_fp32_residual(True); pipe.set_fp16_operands(False)
                 conf, idx, st2 = self._run(x)
                 if st2 & VT_STATUS_NONFINITE:
-                    pipe.set_fp8(was_fp8); pipe.set_fp32_residual(was_res)          # not the checkpoint: one bad image must not change the run
+                    pipe.set_fp8(was_fp8); pipe.set_fp32_residual(was_res); pipe.set_fp16_operands(self.f16)   # not the checkpoint: one bad image must not change the run
                     raise FloatingPointError("non-finite activations even with bf16 operands and fp32 residual storage (inf / NaN pixels or weights?)")
-                print("警告: 激活值超出fp16范围，改用fp32残差存储重新计算该批次")
+                print("警告: 激活值超出fp16范围，改用fp32残差存储" + ("和bf16卷积操作数" if self.f16 else "") + "重新计算该批次")
                 self.fp32_res = True
+                self.f16 = False            # (an overflow of the fp16 storage is an overflow of fp16 operands too: the precision mode ends with it)
                 self.epoch += 1
                 if was_fp8:
                     pipe.set_fp8(True)
@@ -321,9 +323,10 @@ def infer_and_classify(args):
     lo, hi = sharding.shard_range(len(image_paths), rank, world)
     my_paths = image_paths[lo:hi]
     pipe = EncodeTagPipeline(vae_model, decoder)
-    if getattr(args, "fp16_operands", False):
+    f16 = bool(getattr(args, "fp16_operands", False)) and not getattr(args, "fp8", False)
+    if f16:
         pipe.set_fp16_operands(True)
-    tg = _Tagger(pipe, tag_names, args.confidence_threshold, getattr(args, "fp8", False))
+    tg = _Tagger(pipe, tag_names, args.confidence_threshold, getattr(args, "fp8", False), f16)
     bs = max(1, int(getattr(args, "batch_size", 8)))
     host_resize = bool(getattr(args, "host_resize", False))
     serial = bool(getattr(args, "serial", False))
