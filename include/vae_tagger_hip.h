@@ -122,7 +122,9 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         0 (default) = as a standalone HBM-bound pass (one read + one bf16 write of the tensor).
  * flag 3: two-workgroups-per-CU tiles of the halo conv: 3 (default) = every plain-input layer on the
  *         4-wave x 256-VGPR tile (16x16 px x 128 couts), 2 = only the 128-cout layers on it, 1 = the 128-cout layers on
- *         the 8-wave x 128-VGPR tile, 0 = one workgroup per CU (16x16 px x 256 couts / 32x16 px x 128 couts).
+ *         the 8-wave x 128-VGPR tile, 0 = one workgroup per CU (16x16 px x 256 couts / 32x16 px x 128 couts);
+ *         4 = the round-4 experiment tile: ONE wave per SIMD (4 waves x 512 registers, accumulators in AGPRs, 32x16 px x 128 couts) --
+ *         bit-identical outputs, 16-21 % slower on bare layer loops; kept for the microbenchmark, never the default.
  * flag 4: 1 (default) = the residual stream between resnet blocks is STORED as fp16 (all arithmetic stays fp32;
  *         halves the HBM traffic of the conv2 epilogues and of norm1) and each block's conv1 output as fp16 instead of
  *         bf16 (read only by norm2), 0 = stored as fp32 / bf16.
