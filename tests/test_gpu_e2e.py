@@ -370,7 +370,8 @@ def test_config4_fp8_operands_keep_the_logits_within_tolerance(vae, res):
     x = synth.synth_images(2, res, res, seed=3)
     sd_e = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
     sd_d = synth.synth_state_dict(synth.attention_decoder_manifest(n), seed=1)
-    ref_lat = encoder_ref.vae_wrapper_encode(sd_e, x)
+    nref = 1 if res >= 1024 else 2                            # (the CPU oracle needs ~10 s per 1024^2 image: one of the two there)
+    ref_lat = encoder_ref.vae_wrapper_encode(sd_e, x[:nref])
     ref_logits = decoder_ref.attention_decoder_forward(sd_d, ref_lat)
     try:
         pipe.ctx.call("vt_set_flag", 11, 1)
@@ -379,13 +380,13 @@ def test_config4_fp8_operands_keep_the_logits_within_tolerance(vae, res):
     finally:
         pipe.ctx.call("vt_set_flag", 11, 0)
     assert pipe.status() == 0 and torch.equal(again, logits)
-    dl = (lat.cpu() - ref_lat)
-    dg = (logits.cpu() - ref_logits).abs().max().item()
+    dl = (lat[:nref].cpu() - ref_lat)
+    dg = (logits[:nref].cpu() - ref_logits).abs().max().item()
     print(f"fp8 {res}^2: max|dlatent| {dl.abs().max():.3e} rms {dl.pow(2).mean().sqrt():.3e}  max|dlogit| {dg:.3e}")
     assert dg <= 1e-2
     assert dl.abs().max().item() <= FP8_LATENT_MAX and dl.pow(2).mean().sqrt().item() <= FP8_LATENT_RMS
     bf16_logits = pipe.logits(x.cuda())                       # back on bf16 operands: the tight tolerance again
-    assert (bf16_logits.cpu() - ref_logits).abs().max().item() <= 1e-3
+    assert (bf16_logits[:nref].cpu() - ref_logits).abs().max().item() <= 1e-3
 
 
 @pytest.mark.parametrize("shape", [1, 2, 5, 6])
@@ -809,8 +810,7 @@ def test_config4_fp8_with_peaky_attention_rows_through_to_the_logits(res, gain):
     m.load_state_dict(sd_e, strict=False)
     w = DiffusersVAEWrapper(m).to("cuda").eval()
     pipe = EncodeTagPipeline(w, _decoder(n))
-    x = synth.synth_images(2, res, res, seed=int(gain) * 10 + res)
-    taps = {}
+    x = synth.synth_images(2 if res < 512 else 1, res, res, seed=int(gain) * 10 + res)
     ref_lat = encoder_ref.vae_wrapper_encode(sd_e, x)
     ref_logits = decoder_ref.attention_decoder_forward(sd_d, ref_lat)
     bf16_logits = pipe.logits(x.cuda())
@@ -834,7 +834,7 @@ def test_config4_fp8_with_peaky_attention_rows_through_to_the_logits(res, gain):
     assert st == 0 and st_exact == 0
     assert db <= 1e-3
     assert dg <= 1e-2 and dge <= 1e-2
-    for i in range(2):
+    for i in range(x.shape[0]):
         _check_tag_order(pipe, logits[i:i + 1], ref_logits[i:i + 1], f"fp8 peaky x{gain} {res}^2 image {i}")
 
 
