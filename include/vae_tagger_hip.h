@@ -178,6 +178,8 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         then holds one channel chunk of two neighbouring pixels, the halves of a row's two planes staged three K-steps apart, instead of
  *         two chunks of one pixel staged nine K-steps apart, by when the line has left the L2 (every line was fetched twice);
  *         0 = NHWC.  Same arithmetic, same bits.
+ * flag 20: 1 (default) = conv_out (512 -> 32 channels, the moments / mode() epilogue) on its own 32-cout halo tile (conv_out_halo.hip: the
+ *         18 x 18 halo of a 16 x 16-pixel tile and the chunk's nine weight tiles staged once per 32-channel chunk); 0 = the generic GEMM.
  */
 int vt_set_flag(vt_context* ctx, int flag, int value);
 

@@ -974,3 +974,37 @@ def test_planar_downsample_input_is_bit_identical(vae, mode):
         ctx.call("vt_set_flag", 11, 0)
         ctx.call("vt_set_flag", 18, 0)
         vae.check_finite = old_check
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (72, 88), (128, 192), (264, 136), (512, 512)])
+def test_conv_out_on_its_halo_tile_matches_the_generic_gemm(vae, h, w):
+    """vt_set_flag(ctx, 20, v): conv_out (512 -> 32, the moments / mode() epilogue) on conv_out_halo.hip's 32-cout halo tile
+    (default) against the generic GEMM (0): the same bf16 products summed in another order -- moments (all 32 channels) and the scaled mode()
+    (first 16, * 0.3611 + 0.1159) within 2e-3 of each other, both within tolerance of the oracle; latent sizes that are not multiples of
+    the 16 x 16 tile (9 x 11, 33 x 17) and one below a tile (8 x 8); fp16-operand form included."""
+    sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    x = synth.synth_images(2, h, w, seed=h + 2 * w)
+    ref_m = encoder_ref.encoder_moments(sd, x) if h * w <= 128 * 192 else None
+    ctx = vae.vae._context()
+    xd = x.cuda()
+    try:
+        for f16 in (0, 1):
+            ctx.call("vt_set_flag", 18, f16)
+            ctx.call("vt_set_flag", 20, 0)
+            m0 = vae.vae.encode(xd).latent_dist.parameters.clone()
+            z0 = vae.encode(xd).clone()
+            ctx.call("vt_set_flag", 20, 1)
+            m1 = vae.vae.encode(xd).latent_dist.parameters
+            z1 = vae.encode(xd)
+            assert m1.shape == m0.shape == (2, 32, h // 8, w // 8) and z1.shape == (2, 16, h // 8, w // 8)
+            dm, dz = (m1 - m0).abs().max().item(), (z1 - z0).abs().max().item()
+            print(f"{w}x{h} fp16 operands {f16}: conv_out halo tile vs generic GEMM: max|dmoments| {dm:.2e}, max|dlatent| {dz:.2e}")
+            assert torch.isfinite(m1).all() and dm <= 2e-3 and dz <= 1e-3
+            assert torch.allclose(m1[:, :16] * 0.3611 + 0.1159, z1, atol=1e-6)
+            assert torch.equal(vae.encode(xd), z1)
+            if ref_m is not None:
+                assert (m1.cpu() - ref_m).abs().max().item() <= 3e-2     # un-scaled moments: 1e-2 / 0.3611
+    finally:
+        ctx.call("vt_set_flag", 18, 0)
+        ctx.call("vt_set_flag", 20, 1)
+    assert ctx.status() == 0

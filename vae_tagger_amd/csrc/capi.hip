@@ -25,6 +25,7 @@ struct HostTensor {
 struct ConvW {
     const bf16_t* w = nullptr; const bf16_t* wp = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0;   // w: [cout][tap][cin]; wp: halo-kernel packing
     const bf16_t* wp2 = nullptr;        // stride-2 phase-plane kernel's packing (conv3x3_s2_halo.hip)
+    const bf16_t* wpo = nullptr; const bf16_t* wpo16 = nullptr;   // conv_out_halo.hip's packing [cin/32][tap][32 couts][32] (bf16 / fp16 bits), Cout == 32 only
     // the same three layouts holding fp16 bits (vt_set_flag 18: fp16 operands for the convs); w16 only for Cout <= 32 (conv_out)
     const bf16_t* w16 = nullptr; const bf16_t* wp16 = nullptr; const bf16_t* wp2_16 = nullptr;
     const unsigned char* wp8 = nullptr; const float* mult8 = nullptr;   // fp8 halo kernel: e4m3 weights / per-cout (scale / act_scale)
@@ -156,6 +157,7 @@ struct vt_context {
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
     int proj_fp8 = 1;               // vt_set_flag(ctx, 15, v): with the fp8 attention, the q | k and v projections on e4m3 operands too, writing q8 | k8 and v8^T directly
     int attn_fp8 = 1;               // vt_set_flag(ctx, 14, v): in fp8 mode (flag 11) Q.K^T and P.V run on e4m3 operands too (attn_fp8.hip)
+    int conv_out_halo = 1;          // vt_set_flag(ctx, 20, v): conv_out on its 32-cout halo tile (conv_out_halo.hip) instead of the generic GEMM
     int s2_planar = 1;              // vt_set_flag(ctx, 19, v): the 16-bit / e4m3 copy of a stage's output that feeds its stride-2 conv is written chunk-planar
                                     // ([C/32 or C/64][H][W][chunk]) so that both halves of every 128-B line are staged three K-steps apart, not nine
     int f16_ops = 0;                // vt_set_flag(ctx, 18, v): fp16 instead of bf16 operands for the convs (same 2 B, 11 significand bits instead of 8)
@@ -269,6 +271,20 @@ int get_conv(vt_context* c, const std::string& name, int cout, int cin, int k, C
         if (k == 3 && cout <= 32) {
             out->w16 = (const bf16_t*)c->upload(ph.data(), ph.size() * 2);
             if (!out->w16) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
+        }
+        if (k == 3 && vt_conv_out_halo_supported(cin, cout)) {
+            // conv_out's own halo tile: [cin/32][tap = ky * 3 + kx][cout][32], both operand types
+            std::vector<uint16_t> ob(p.size()), oh(p.size());
+            for (int o = 0; o < cout; ++o)
+                for (int t = 0; t < 9; ++t)
+                    for (int i = 0; i < cin; ++i) {
+                        const size_t d = (((size_t)(i >> 5) * 9 + t) * cout + o) * 32 + (i & 31);
+                        ob[d] = p[((size_t)o * 9 + t) * cin + i];
+                        oh[d] = ph[((size_t)o * 9 + t) * cin + i];
+                    }
+            out->wpo = (const bf16_t*)c->upload(ob.data(), ob.size() * 2);
+            out->wpo16 = (const bf16_t*)c->upload(oh.data(), oh.size() * 2);
+            if (!out->wpo || !out->wpo16) return c->fail(VT_ERR_HIP, "upload failed for %s", name.c_str());
         }
         if (out->wp) {
             for (int o = 0; o < cout; ++o)
@@ -1394,8 +1410,30 @@ int vt_encode(vt_context* c, const float* x, int B, int H, int W, int mode, floa
         cur = nxt;
     }
     if ((r = resnet(e.mid1, nullptr, false))) return r;
-    const bool out16 = e.conv_out.cout <= 32 && e.conv_out.w16 && c->f16_ops && !c->fp8;      // fp16-operand mode: conv_out on the 32-cout GEMM tile's fp16 form
+    const bool out16 = e.conv_out.cout <= 32 && e.conv_out.w16 && c->f16_ops && !c->fp8;      // fp16-operand mode: conv_out multiplies fp16 too (both of its kernels have the form)
     if ((r = run_gn(c, f32[cur], rdt, B, h * w, e.norm_out, e.groups, 1, act, gn, s, false, out16))) return r;
+    if (c->conv_out_halo && e.conv_out.wpo && e.conv_out.k == 3 && (mode == 0 ? 2 * e.latent : e.latent) <= e.conv_out.cout) {
+        // conv_out -> moments (mode 0) / mode() = the first `latent` channels (mode 1) / * scaling + shift (mode 2), on its 32-cout halo tile
+        ConvOutArgs o{};
+        const ConvW& cw = e.conv_out;
+        o.X = act; o.Wp = out16 ? cw.wpo16 : cw.wpo; o.f16 = out16; o.bias = cw.b; o.out = latent; o.zeros = c->zeros;
+        o.batch = B; o.H = h; o.W = w; o.Cin = cw.cin; o.Cout = cw.cout; o.keep = mode == 0 ? 2 * e.latent : e.latent;
+        o.post_scale = (mode == 2 && e.has_scaling) ? e.scaling : 1.f;
+        o.post_shift = (mode == 2 && e.has_shift) ? e.shift : 0.f;
+        if (c->profiling) {
+            vt_context::ProfRec pr;
+            pr.e0 = c->next_event(); pr.e1 = c->next_event();
+            if (!pr.e0 || !pr.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+            pr.flops = 2.0 * B * (double)h * w * cw.cout * 9.0 * cw.cin; pr.cfg = VT_PROF_CONV_OUT;
+            HIPCK(c, hipEventRecord(pr.e0, s), "hipEventRecord");
+            HIPCK(c, vt_launch_conv_out_halo(o, s), "conv_out_halo");
+            HIPCK(c, hipEventRecord(pr.e1, s), "hipEventRecord");
+            c->prof.push_back(pr);
+        } else {
+            HIPCK(c, vt_launch_conv_out_halo(o, s), "conv_out_halo");
+        }
+        return VT_OK;
+    }
     {
         // conv_out -> moments; mode() = mean = first `latent` channels; optional * scaling + shift
         ConvGemmArgs a{};
@@ -1626,6 +1664,7 @@ int vt_set_flag(vt_context* c, int flag, int value) {
     if (flag == 17) { c->attn_proj_kernel = value != 0; return VT_OK; }
     if (flag == 18) { c->f16_ops = value != 0; return VT_OK; }
     if (flag == 19) { c->s2_planar = value != 0; return VT_OK; }
+    if (flag == 20) { c->conv_out_halo = value != 0; return VT_OK; }
     if (flag == 13) { c->s2_halo = value != 0; return VT_OK; }
     if (flag == 14) { c->attn_fp8 = value != 0; return VT_OK; }
     if (flag == 15) { c->proj_fp8 = value != 0; return VT_OK; }

@@ -511,6 +511,6 @@ const char* vt_conv_gemm_config_name(int cfg) {
                                                "conv_gemm_kernel<256,256,2,4>", "conv3x3_halo_kernel<2,2,0,8,4>",
                                                "conv3x3_halo_kernel<4,2,0,4,4>", "conv3x3_halo_kernel<4,2,0,8,6>",
                                                "conv3x3_halo_kernel<2,4,0,8,6>", "conv3x3_halo_kernel<.,.,1,8,6>",
-                                               "conv3x3_halo_kernel<.,.,2,8,6>", "conv_gemm_kernel<192,128,4,2,occ2>", "attn_qk_kernel", "conv3x3_halo_fp8_kernel", "attn_pv_kernel", "conv_gemm_fp8_kernel", "conv3x3_s2_halo_kernel", "attn_qk_fp8_kernel", "attn_pv_fp8_kernel", "conv3x3_s2_halo_fp8_kernel", "proj_fp8_kernel", "conv3x3_halo_fp8_kernel", "attn_qk_kernel<4> (projections)", "gn_apply_kernel"};
+                                               "conv3x3_halo_kernel<.,.,2,8,6>", "conv_gemm_kernel<192,128,4,2,occ2>", "attn_qk_kernel", "conv3x3_halo_fp8_kernel", "attn_pv_kernel", "conv_gemm_fp8_kernel", "conv3x3_s2_halo_kernel", "attn_qk_fp8_kernel", "attn_pv_fp8_kernel", "conv3x3_s2_halo_fp8_kernel", "proj_fp8_kernel", "conv3x3_halo_fp8_kernel", "attn_qk_kernel<4> (projections)", "conv_out_halo_kernel", "gn_apply_kernel"};
     return (cfg >= 0 && cfg < VT_NUM_PROF_SLOTS) ? n[cfg] : "?";
 }

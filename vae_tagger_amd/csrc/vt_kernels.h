@@ -61,8 +61,9 @@ constexpr int VT_PROF_S2_HALO_FP8 = 17;  // stride-2 phase-plane conv on e4m3 op
 constexpr int VT_PROF_PROJ_FP8 = 18;     // fp8 mode's q | k and v projections (attn_fp8.hip, proj_fp8_kernel)
 constexpr int VT_PROF_HALO_FP8_C128 = 19; // the fp8 halo conv's launches with Cin <= 128 (18 K-steps per tile), same kernel name as slot 11: tools read them apart
 constexpr int VT_PROF_PROJ_BF16 = 20;    // bf16 q | k and v^T projections on attn_qk_kernel<4> (round 4)
-constexpr int VT_PROF_GN_APPLY = 21;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
-constexpr int VT_NUM_PROF_SLOTS = 22;
+constexpr int VT_PROF_CONV_OUT = 21;     // conv_out on its 32-cout halo tile (conv_out_halo.hip, round 4)
+constexpr int VT_PROF_GN_APPLY = 22;     // HBM-bound GroupNorm(+SiLU) apply pass: 'flops' slot carries algorithmic BYTES (last slot)
+constexpr int VT_NUM_PROF_SLOTS = 23;
 
 // Q.K^T of the mid-block attention with the softmax numerators in the epilogue (attn_qk.hip; d = 512 only)
 struct AttnQkArgs {
@@ -266,6 +267,21 @@ int vt_conv3x3_halo_fp8_tiles(int H, int W);              // GroupNorm partials 
 int vt_conv3x3_halo_fp8_tiles_shape(int H, int W, int shape);
 int vt_halo_fp8_row_of_cout(int cout_local /*0..31*/);
 hipError_t vt_launch_conv3x3_halo_fp8(const Conv3x3Fp8Args& a, hipStream_t s);
+
+// conv_out (Conv2d(Cin, 32, 3, pad 1)) on a 32-cout halo tile (conv_out_halo.hip): out[b][c][y][x] = (W . x + bias)[c] * post_scale + post_shift for the
+// first `keep` channels, fp32 NCHW -- the moments / mode() * scaling + shift epilogue of DiffusersVAEWrapper.encode (diffusers_vae_loader.py:78-86)
+struct ConvOutArgs {
+    const bf16_t* X;        // NHWC 16-bit [batch][H][W][Cin] (bf16, or fp16 bits with f16)
+    const bf16_t* Wp;       // packed [Cin/32][9 taps (ky * 3 + kx)][32 couts][32] 16-bit
+    const float* bias;      // [32] or null
+    float* out;             // [batch][keep][H][W] fp32
+    const void* zeros;
+    int batch, H, W, Cin, Cout, keep;
+    float post_scale, post_shift;
+    int f16;
+};
+bool vt_conv_out_halo_supported(int Cin, int Cout);
+hipError_t vt_launch_conv_out_halo(const ConvOutArgs& a, hipStream_t s);
 
 // conv_in: fp32 NCHW image -> NHWC 128-channel fp32 (+ optional bf16) rows, direct fp32 conv 3x3 p1.
 // gn_partial (optional): (n, mean, M2) triples of the output, [B][parts][Cout/gn_cpg][3]; *gn_parts receives `parts`.
