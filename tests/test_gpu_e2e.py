@@ -1008,3 +1008,32 @@ def test_conv_out_on_its_halo_tile_matches_the_generic_gemm(vae, h, w):
         ctx.call("vt_set_flag", 18, 0)
         ctx.call("vt_set_flag", 20, 1)
     assert ctx.status() == 0
+
+
+@pytest.mark.parametrize("h,w", [(72, 88), (128, 192), (264, 136), (512, 512)])
+def test_attention_linear_layers_on_the_qk_skeleton_match_the_generic_gemm(vae, h, w):
+    """vt_set_flag(ctx, 17, v): the attention's q | k, v^T and to_out linear layers on attn_qk.hip's skeleton (modes 4 / 5: one operand's rows in
+    registers, the other's streamed; to_out with the residual add, fp16 / fp32 stores and the GroupNorm partials of the next norm in its
+    epilogue) against the generic GEMM (0), through the whole encoder: token counts that are not multiples of 32 / 64 / 256 (99, 561), both
+    residual storage types (flag 4), latents within 2e-3 of each other and within tolerance of the oracle, deterministic, status clear."""
+    sd = synth.synth_state_dict(synth.encoder_manifest(), seed=0)
+    x = synth.synth_images(2, h, w, seed=3 * h + w)
+    ref = encoder_ref.vae_wrapper_encode(sd, x) if h * w <= 264 * 136 else None
+    ctx = vae.vae._context()
+    xd = x.cuda()
+    try:
+        for res16 in (1, 0):
+            ctx.call("vt_set_flag", 4, res16)
+            ctx.call("vt_set_flag", 17, 0)
+            z0 = vae.encode(xd).clone()
+            ctx.call("vt_set_flag", 17, 1)
+            z1 = vae.encode(xd)
+            d = (z1 - z0).abs().max().item()
+            print(f"{w}x{h} (S = {(h // 8) * (w // 8)}), fp16 residual storage {res16}: linear layers on the Q.K^T skeleton vs generic GEMM: max|dlatent| {d:.2e}")
+            assert torch.isfinite(z1).all() and d <= 2e-3 and torch.equal(vae.encode(xd), z1)
+            if ref is not None:
+                assert (z1.cpu() - ref).abs().max().item() <= TOL_LATENT_BF16
+    finally:
+        ctx.call("vt_set_flag", 4, 1)
+        ctx.call("vt_set_flag", 17, 1)
+    assert ctx.status() == 0

@@ -15,6 +15,9 @@
 // mode 4 (round 4): the same skeleton as a linear layer of K = 512 (the attention's q | k and v^T projections): rows of one operand in
 //         registers, the other operand's rows streamed as "keys", out = bf16(alpha * q.k + kbias[key] + qbias[row]) row-major.  The generic
 //         GEMM ran these two launches at 0.5 PF (K = 512 is 8 of its K-steps: a tile lives in its prologue and epilogue).
+// mode 5 (round 4): mode 4 with the attention's to_out epilogue: + residual stream, fp16 / fp32 stores, and GroupNorm (n, mean, M2) partials of the
+//         result per (32-row slab of a wave, group of 16 output channels) for the norm that follows -- the last launch of the default path that
+//         was still on the generic GEMM.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -45,9 +48,10 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     const int b = logical / per_img, qs = logical - b * per_img;
     const int qt = qs / nsplit, ksp = qs - qt * nsplit;           // the splits of a query block are neighbours: they share its Q rows in L2
     const bf16_t* qb = a.q + (long long)b * a.qk_bs;
-    const bf16_t* kb = a.k + (long long)b * (MODE == 4 ? a.k_bs : a.qk_bs);
-    const int nkeys = MODE == 4 ? a.nk : a.S;                     // rows of the streamed operand
-    const int ldk = MODE == 4 ? a.ldk : a.ldq;
+    constexpr bool LIN = MODE == 4 || MODE == 5;                  // linear-layer forms: separate operands, key tiles split evenly
+    const bf16_t* kb = a.k + (long long)b * (LIN ? a.k_bs : a.qk_bs);
+    const int nkeys = LIN ? a.nk : a.S;                           // rows of the streamed operand
+    const int ldk = LIN ? a.ldk : a.ldq;
     const int row0 = qt * QB + wave * 32;
 
     // ---- this wave's Q slab: B operand of k-step ks for row tile j = q[row0 + 16 j + fr][32 ks + 8 fq .. +8]
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     for (int j = 0; j < 2; ++j) {
         const int row = row0 + j * 16 + fr;
         rv[j] = MODE == 1 ? -__builtin_inff() : 0.f;
-        if (MODE == 4) sh2[j] = (a.qbias && row < a.S) ? a.qbias[row] : 0.f;          // (mode 4: the row's bias)
+        if (LIN) sh2[j] = (a.qbias && row < a.S) ? a.qbias[row] : 0.f;                // (linear forms: the row's bias)
         else sh2[j] = (MODE >= 2 && row < a.S) ? a.rowin[(long long)b * a.row_bs + row] * 1.44269504f : 0.f;
     }
     const float alpha2 = a.alpha * 1.44269504f;
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     const int sr = lane >> 2, sp = lane & 3;                   // after the permute: this lane stores row sr, piece sp
     const int perm_addr = (sp * 16 + sr) << 2;                 // ... which it takes from lane 16 sp + sr
     auto store_held = [&](int kt_prev) __attribute__((always_inline)) {
+        if constexpr (MODE == 5) return;                       // (stored by its epilogue, in accumulator layout)
         if constexpr (MODE == 3) {
             // fragment order (attn_pv.hip): piece (j, h) of this lane as it stands -- 1 KB contiguous per store instruction,
             // the wave's stream over the key tiles sequential in memory
@@ -148,6 +153,70 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     auto epilogue_t = [&](int kt, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int key0 = kt * KT + 8 * fq;
+        if constexpr (MODE == 5) {
+            // lane (fq, fr): rows row0 + 16 j + fr, runs h = 0 / 1 = keys key0 + 32 h .. + 7 (tiles i = 2 h, 2 h + 1): 16-B fp16 (32-B fp32) pieces of
+            // the residual and of the output; the GroupNorm group of run h is (kt * 64 + 32 h + 8 fq) / 16: shared by the lane pair fq ^ 1
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            const int nrows = a.S - row0 < 0 ? 0 : (a.S - row0 > 32 ? 32 : a.S - row0);      // valid rows of this wave's slab (wave-uniform)
+            const long long ob = (long long)b * a.p_bs;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kk = key0 + 32 * h;
+                const bool kreal = FULL || kk + 7 < nkeys;       // (nk is a multiple of 16: a run is real or padding as a whole)
+                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+                if (a.kbias && kreal) { b0 = *(const f32x4*)(a.kbias + kk); b1 = *(const f32x4*)(a.kbias + kk + 4); }
+                float v[2][8];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = row0 + j * 16 + fr;
+                    const bool ok = row < a.S && kreal;
+                    const long long o = ob + (long long)row * a.ldp + kk;
+                    float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (ok && a.res_f16) {
+                        const f16x8 rh = *(const f16x8*)(a.res_f16 + o);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rs[e] = (float)rh[e];
+                    } else if (ok && a.res_f32) {
+                        const f32x4 r0 = *(const f32x4*)(a.res_f32 + o), r1 = *(const f32x4*)(a.res_f32 + o + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { rs[e] = r0[e]; rs[4 + e] = r1[e]; }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        v[j][e] = fmaf(acc[2 * h + (e >> 2)][j][e & 3], a.alpha, (e < 4 ? b0[e & 3] : b1[e & 3]) + sh2[j]) + rs[e];
+                    if (ok && a.out_f16) {
+                        f16x8 oh;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) oh[e] = (f16_t)v[j][e];
+                        *(f16x8*)(a.out_f16 + o) = oh;
+                    } else if (ok && a.out_f32) {
+                        *(f32x4*)(a.out_f32 + o) = f32x4{v[j][0], v[j][1], v[j][2], v[j][3]};
+                        *(f32x4*)(a.out_f32 + o + 4) = f32x4{v[j][4], v[j][5], v[j][6], v[j][7]};
+                    }
+                }
+                if (a.gn_partial && kreal) {
+                    // (n, mean, M2) of the slab's rows x the group's 16 keys, relative to a pivot (the group's first value of the slab's first row)
+                    const float piv = __shfl(v[0][0], lane & 32, 64);
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (row0 + j * 16 + fr < a.S) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float d = v[j][e] - piv; s1 += d; s2 = fmaf(d, d, s2); }
+                        }
+                    }
+                    s1 = vt_row16_sum(s1); s2 = vt_row16_sum(s2);
+                    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+                    if (fr == 0 && (fq & 1) == 0) {
+                        const float n = (float)nrows * 16.f;
+                        const float ms = n > 0.f ? s1 / n : 0.f;
+                        float* d = a.gn_partial + (((long long)b * a.gn_parts + (row0 >> 5)) * (nkeys >> 4) + (kk >> 4)) * 3;
+                        d[0] = n; d[1] = n > 0.f ? piv + ms : 0.f; d[2] = n > 0.f ? fmaxf(s2 - s1 * ms, 0.f) : 0.f;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -219,8 +288,8 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
     const bool late = (wave & 4) != 0;
     const int seg0 = ksp * (4 / nsplit), seg1 = (ksp + 1) * (4 / nsplit);      // nsplit = 1, 2 or 4: whole segments per workgroup
     // this workgroup's key tiles [kt0, nkt): whole segments in the fragment-order mode, an even share of the tiles in the linear mode
-    const int kt0 = MODE == 3 ? segb[seg0] : MODE == 4 ? (int)((long long)ksp * nkt_all / nsplit) : 0;
-    const int nkt = MODE == 3 ? segb[seg1] : MODE == 4 ? (int)((long long)(ksp + 1) * nkt_all / nsplit) : nkt_all;
+    const int kt0 = MODE == 3 ? segb[seg0] : LIN ? (int)((long long)ksp * nkt_all / nsplit) : 0;
+    const int nkt = MODE == 3 ? segb[seg1] : LIN ? (int)((long long)(ksp + 1) * nkt_all / nsplit) : nkt_all;
     const bool counted = MODE == 3 && row0 < a.S;              // this wave issues exactly 4 stores per epilogue
     stage(kt0, kt0 & 1);
     for (int kt = kt0; kt < nkt; ++kt) {
@@ -264,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
         epilogue(nkt - 1);
         if (MODE >= 2) store_held(nkt - 1);
     }
-    if constexpr (MODE == 4) return;
+    if constexpr (LIN) return;
     if (MODE == 3) {
         // empty segments (fewer than four key tiles) still have a defined sum
 #pragma unroll
@@ -289,7 +358,25 @@ __global__ __launch_bounds__(512, 2) void attn_qk_kernel(const AttnQkArgs a) {
 
 bool vt_attn_qk_supported(int S, int C) { return C == D && S > 0; }
 
+int vt_attn_linear_parts(int S) { return (S + QB - 1) / QB * 8; }      // 32-row slabs launched per image (mode 5's GroupNorm partials)
+
 hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s) {
+    if (a.mode == 5) {
+        if (!a.q || !a.k || !a.zeros || a.batch <= 0 || !vt_attn_qk_supported(a.S, a.C) || a.nk <= 0 || (a.nk % 16) || a.gate) return hipErrorInvalidValue;
+        if ((a.out_f16 != nullptr) == (a.out_f32 != nullptr) || (a.res_f16 && a.res_f32)) return hipErrorInvalidValue;
+        if ((a.ldq % 8) || (a.ldk % 8) || (a.qk_bs % 8) || (a.k_bs % 8) || (a.ldp % 8) || (a.p_bs % 8) || a.ldp < a.nk) return hipErrorInvalidValue;
+        if ((long long)a.S * a.ldq >= (1LL << 31) || (long long)a.nk * a.ldk >= (1LL << 31)) return hipErrorInvalidValue;
+        if (a.gn_partial && a.gn_parts != vt_attn_linear_parts(a.S)) return hipErrorInvalidValue;
+        const int nsp = a.nsplit > 1 ? a.nsplit : 1;
+        if (nsp > (a.nk + KT - 1) / KT) return hipErrorInvalidValue;
+        const long long nblk5 = (long long)((a.S + QB - 1) / QB) * a.batch * nsp;
+        if (nblk5 > 0x7fffffffLL) return hipErrorInvalidValue;
+        static std::atomic<unsigned long long> attr5{0};
+        hipError_t e5 = vt_once_per_device(attr5, [&] { return hipFuncSetAttribute((const void*)attn_qk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF); });
+        if (e5 != hipSuccess) return e5;
+        hipLaunchKernelGGL(attn_qk_kernel<5>, dim3((unsigned)nblk5), dim3(512), 2 * KBUF, s, a);
+        return hipGetLastError();
+    }
     if (a.mode == 4) {
         if (!a.q || !a.k || !a.P || !a.zeros || a.batch <= 0 || !vt_attn_qk_supported(a.S, a.C) || a.nk <= 0 || a.gate) return hipErrorInvalidValue;
         if ((a.ldq % 8) || (a.ldk % 8) || (a.qk_bs % 8) || (a.k_bs % 8) || (a.ldp % 8) || (a.p_bs % 8) || a.ldp < (a.nk + 7) / 8 * 8) return hipErrorInvalidValue;

@@ -1027,6 +1027,34 @@ int run_attention(vt_context* c, const AttnW& w, const bf16_t* x16, const void* 
         a.x_stream = 0;
     }
     a.row_mode = 0; a.row_in = nullptr;
+    if (c->attn_proj_kernel && c->attn_qk_kernel && vt_attn_qk_supported(S, C) && (C % 16) == 0) {
+        // out = o Wo^T + bo + residual on attn_qk.hip's skeleton (mode 5): rows = tokens o, keys = Wo (shared by the batch), the residual stream added and
+        // stored as fp16 / fp32 in the epilogue, GroupNorm partials of the result per (32-token slab, 16-channel group) for the norm that follows
+        AttnQkArgs po{};
+        po.mode = 5; po.q = sc.o; po.ldq = C; po.qk_bs = (long long)S * C; po.S = S; po.C = C;
+        po.k = w.wo; po.ldk = C; po.k_bs = 0; po.nk = C; po.kbias = w.bo;
+        po.ldp = C; po.p_bs = (long long)S * C; po.alpha = 1.f; po.batch = B; po.zeros = c->zeros; po.row_bs = S;
+        if (rdt == 1) { po.res_f32 = (const float*)res; po.out_f32 = (float*)out; } else { po.res_f16 = (const f16_t*)res; po.out_f16 = (f16_t*)out; }
+        if (gn) {
+            gn->parts = 0;
+            if (c->fuse_gn_stats && C / groups == 16) { po.gn_partial = gn->partial; po.gn_parts = vt_attn_linear_parts(S); gn->parts = po.gn_parts; }
+        }
+        auto split_for = [](long long qblocks, int nkt) { int n = 1; while (n < nkt && qblocks * n < 512) n *= 2; return n < nkt ? n : nkt; };
+        po.nsplit = split_for((long long)B * ((S + 255) / 256), (C + 63) / 64);
+        if (c->profiling) {
+            vt_context::ProfRec r0;
+            r0.e0 = c->next_event(); r0.e1 = c->next_event();
+            if (!r0.e0 || !r0.e1) return c->fail(VT_ERR_HIP, "event pool exhausted");
+            r0.flops = 2.0 * B * (double)S * C * C; r0.cfg = VT_PROF_PROJ_BF16;
+            HIPCK(c, hipEventRecord(r0.e0, s), "hipEventRecord");
+            HIPCK(c, vt_launch_attn_qk(po, s), "attn out proj");
+            HIPCK(c, hipEventRecord(r0.e1, s), "hipEventRecord");
+            c->prof.push_back(r0);
+        } else {
+            HIPCK(c, vt_launch_attn_qk(po, s), "attn out proj");
+        }
+        return VT_OK;
+    }
     // out = o Wo^T + bo + residual -> fp32 [B][S][C]
     a.X = sc.o; a.W = w.wo; a.bias = w.bo; a.bias_mode = 1; a.out_bf16 = nullptr;
     if (rdt == 1) { a.res = (const float*)res; a.out_f32 = (float*)out; } else { a.res_f16 = (const f16_t*)res; a.out_f16 = (f16_t*)out; }
@@ -1082,6 +1110,7 @@ EncPlan plan_encoder(const EncoderW& e, int B, int H, int W) {
     }
     p.hl = h; p.wl = w;
     const int S = h * w, C = e.block_out.back();
+    if (vt_attn_linear_parts(S) > p.max_chunks) p.max_chunks = vt_attn_linear_parts(S);     // to_out's GroupNorm partials: one per 32-token slab (attn_qk.hip, mode 5)
     const size_t slack = 4096;
     p.total = 3 * align_up(p.max_elems * B * 4 + slack) + 3 * align_up(p.max_elems * B * 2 + slack) +
               align_up((size_t)B * p.max_chunks * e.groups * 3 * 4) + align_up((size_t)B * p.max_c * 2 * 4) +

@@ -88,7 +88,13 @@ struct AttnQkArgs {
     // to the 64-key tile) written as 0; nsplit (any value >= 1) spreads a row block's key tiles over that many workgroups.  The attention's
     // q | k projection (rows = tokens, keys = [Wq; Wk]) and v^T projection (rows = Wv, keys = tokens) run on it instead of the generic GEMM.
     int nk, ldk; long long k_bs; const float* kbias; const float* qbias;
+    // mode 5 (round 4): mode 4's linear layer with the attention's to_out epilogue -- out[b][row][key] = alpha * q[row] . k[key] + kbias[key] +
+    // residual[b][row][key], stored as fp16 (res_f16 / out_f16: the fp16 residual stream) or fp32 (res_f32 / out_f32), row pitch ldp, batch stride
+    // p_bs -- plus GroupNorm (n, mean, M2) partials of what was stored: one triple per (32-row slab, group of 16 keys),
+    // gn_partial[((b * gn_parts + slab) * (nk / 16) + group) * 3], gn_parts = vt_attn_linear_parts(S) slabs per image
+    const f16_t* res_f16; const float* res_f32; f16_t* out_f16; float* out_f32; float* gn_partial; int gn_parts;
 };
+int vt_attn_linear_parts(int S);
 bool vt_attn_qk_supported(int S, int C);
 hipError_t vt_launch_attn_qk(const AttnQkArgs& a, hipStream_t s);
 
