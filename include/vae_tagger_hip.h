@@ -164,8 +164,9 @@ double vt_encoder_flops(const vt_context* ctx, int H, int W);
  *         per CU; 1 = 16 x 32 px, 2 = 8 x 64 px, both on 8 waves, one workgroup per CU (a staged weight tile serves twice the pixels);
  *         applied to the layers with Cin <= 128, or to every layer with value & 4.  The conv outputs are bit-identical for every value (the
  *         GroupNorm partials are per tile, so their merge order -- the last bits of the statistics -- follows the shape).
- * flag 17: 1 (default) = the attention's bf16 q | k and v^T projections run on attn_qk.hip's skeleton (mode 4: one operand's rows in
- *         registers, the other's streamed through LDS, bias + bf16 store in the epilogue); 0 = the generic GEMM (conv_gemm.hip).
+ * flag 17: 1 (default) = the attention's bf16 linear layers run on attn_qk.hip's skeleton: q | k and v^T (mode 4: one operand's rows in
+ *         registers, the other's streamed through LDS, bias + bf16 store in the epilogue) and to_out (mode 5: + residual stream, fp16 / fp32
+ *         stores, GroupNorm partials of the result); 0 = the generic GEMM (conv_gemm.hip).
  * flag 18: 1 = fp16 instead of bf16 MFMA operands for the convolutions (GroupNorm outputs, the 16-bit operand copies and the packed
  *         weights carry fp16 bits: the same 2 B per element, 11 significand bits instead of 8; v_mfma_f32_16x16x32_f16).  Latents move
  *         ~6x closer to the fp32 reference (max |dlatent| 1.5e-3 instead of 1e-2 .. 2e-2 on smooth pictures, where bf16's rounding
