@@ -192,6 +192,11 @@ int vt_set_flag(vt_context* ctx, int flag, int value);
  * pass: its 'flops' entry carries algorithmic BYTES (one read + one bf16 write).  bench.py derives
  * roofline.achieved from these.
  */
+/* diagnostics: between vt_debug_trace(ctx, 1, ...) and vt_debug_trace(ctx, 0, sums, max, &n) every GroupNorm of the encoder records two
+ * order-independent checksums on the launch stream -- of the (n, mean, M2) partials it consumed and of its (scale, shift) table -- in launch order;
+ * the second call synchronises the device and copies them out.  Two runs of the same input give the same list unless some producer's statistics
+ * are not deterministic; the first differing index names the layer (tests/diagnostics/gn_trace_diff.py). */
+int vt_debug_trace(vt_context* ctx, int enable, unsigned long long* sums_out, int max_sums, int* n_out);
 int vt_profile_num_configs(void);
 int vt_profile_begin(vt_context* ctx);
 int vt_profile_end(vt_context* ctx, int max_cfg, long long* launches, double* total_ms, double* total_flops,

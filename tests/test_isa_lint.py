@@ -93,7 +93,7 @@ def test_attention_lds_reads_are_ahead_of_their_mfmas(attention_asm, kernel):
 # CPU, instead of as a few per cent on the GPU.
 _BUDGET = {  # file: {kernel substring: max vgpr_spill_count}
     "conv3x3_halo": {"conv3x3_halo_kernelILi2ELi2ELi0ELi8ELi4ELb0E": 0, "conv3x3_halo_kernelILi2ELi2ELi0ELi8ELi4ELb1E": 0,       # bf16 / fp16 operands
-                     "conv3x3_halo_kernelILi2ELi2ELi0ELi16ELi6ELb0E": 30},   # the one-wave-per-SIMD experiment tile: 256 AGPRs + 256 VGPRs, spills outside the loop
+                     "conv3x3_halo_kernelILi2ELi2ELi0ELi16ELi6ELb0E": 33},   # the one-wave-per-SIMD experiment tile: 256 AGPRs + 256 VGPRs, spills outside the loop
     "conv3x3_halo_fp8": {"conv3x3_halo_fp8_kernelILi2ELi1E": 0, "conv3x3_halo_fp8_kernelILi4ELi1E": 0, "conv3x3_halo_fp8_kernelILi2ELi2E": 0},
     "conv3x3_s2_halo": {"conv3x3_s2_halo_kernelILb0E": 3, "conv3x3_s2_halo_kernelILb1E": 3},            # three, in the last chunk's epilogue hand-over, none in the steady-state loop
     "conv3x3_s2_halo_fp8": {"conv3x3_s2_halo_fp8_kernel": 0},
@@ -126,3 +126,33 @@ def test_mfma_kernels_keep_two_waves_per_simd_without_spilling(budget_asm, name)
         one_wave = "ELi16ELi6E" in k                                # the one-wave-per-SIMD experiment tile: 256 VGPRs + 256 AGPRs by design
         assert int(b["vgpr_count"]) <= (512 if one_wave else 256), (k, b["vgpr_count"])
         assert int(b["vgpr_spill_count"]) <= max_spill and int(b["sgpr_spill_count"]) == 0, (k, b["vgpr_spill_count"], b["sgpr_spill_count"])
+
+
+# ---- round 4: packed fp32 with a source op_sel.  `v_pk_add_f32 d, a, p op_sel:[0,1]` (the HIGH register of a pair routed into the LOW lane) read
+# 0.0 in lanes 48..63 on some executions when it was the first reader of a ds_bpermute result: one element of one GroupNorm partial summed against
+# pivot 0, so ragged shapes encoded differently run to run (vt_common.h, VT_PIN_PAIR / VT_NO_PACKED_F32).  No kernel of the BUILT
+# library may contain such an instruction (op_sel_hi -- low register into the high lane -- is what the compiler emits for pinned pairs, and is stable).
+def test_no_packed_fp32_instruction_routes_a_source_by_op_sel(tmp_path):
+    from vae_tagger_amd import _lib
+    objdump = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin", "llvm-objdump")
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(objdump)):
+        pytest.skip("needs the built library and llvm-objdump")
+    so = tmp_path / "lib.so"
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], check=True, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)   # unbundles next to the copy
+    objs = sorted(p for p in os.listdir(tmp_path) if p.endswith("gfx950"))
+    assert len(objs) >= 10, objs                                   # one code object per translation unit
+    packed = bad = 0
+    kernel = None
+    offenders = set()
+    for o in objs:
+        for l in subprocess.run([objdump, "-d", str(tmp_path / o)], check=True, stdout=subprocess.PIPE, text=True).stdout.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\w+)>:", l)
+            if m:
+                kernel = m.group(1)
+            elif re.search(r"\bv_pk_(add|mul|fma)_f32\b", l):
+                packed += 1
+                if re.search(r"op_sel:\[", l):
+                    bad += 1; offenders.add(kernel)
+    assert packed > 1000                                           # the epilogues do use packed fp32
+    assert bad == 0, sorted(offenders)

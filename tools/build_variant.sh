@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../vae_tagger_amd/csrc"
 name=$1; defs=$2
 mkdir -p exp/obj_$name
-for f in conv_gemm conv3x3_halo conv3x3_s2_halo conv3x3_s2_halo_fp8 conv3x3_halo_fp8 attn_qk attn_pv attn_fp8 groupnorm misc_kernels decoder capi; do
+for f in $(sed -n 's/^SRCS = //p' Makefile | sed 's/\.hip//g'); do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast $defs -c $f.hip -o exp/obj_$name/$f.o &
 done
 wait

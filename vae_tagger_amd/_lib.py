@@ -44,6 +44,7 @@ PROTOTYPES = {
     "vt_resize_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "vt_encoder_flops": (_c.c_double, [_vp, _i, _i]),
     "vt_set_flag": (_i, [_vp, _i, _i]),
+    "vt_debug_trace": (_i, [_vp, _i, _c.POINTER(_c.c_ulonglong), _i, _c.POINTER(_i)]),
     "vt_profile_num_configs": (_i, []),
     "vt_profile_begin": (_i, [_vp]),
     "vt_profile_end": (_i, [_vp, _i, _c.POINTER(_ll), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_char_p)]),

@@ -157,6 +157,8 @@ struct vt_context {
     int gemm_short = 1;             // vt_set_flag(ctx, 6, v): short-K GEMM launches on the two-workgroups-per-CU tile
     int proj_fp8 = 1;               // vt_set_flag(ctx, 15, v): with the fp8 attention, the q | k and v projections on e4m3 operands too, writing q8 | k8 and v8^T directly
     int attn_fp8 = 1;               // vt_set_flag(ctx, 14, v): in fp8 mode (flag 11) Q.K^T and P.V run on e4m3 operands too (attn_fp8.hip)
+    // diagnostics (vt_debug_trace): order-independent checksums of every GroupNorm's (scale, shift) table, in launch order
+    unsigned long long* dbg = nullptr; int dbg_n = 0; bool dbg_on = false;
     int conv_out_halo = 1;          // vt_set_flag(ctx, 20, v): conv_out on its 32-cout halo tile (conv_out_halo.hip) instead of the generic GEMM
     int s2_planar = 1;              // vt_set_flag(ctx, 19, v): the 16-bit / e4m3 copy of a stage's output that feeds its stride-2 conv is written chunk-planar
                                     // ([C/32 or C/64][H][W][chunk]) so that both halves of every 128-B line are staged three K-steps apart, not nine
@@ -485,6 +487,19 @@ struct GnState {
     int parts = 0;            // triples per (image, group) currently in `partial`; 0 = none
 };
 
+// diagnostics: sum of the 32-bit words of a buffer (integer adds commute: the same bytes give the same sum whatever the thread order)
+__global__ void dbg_checksum_kernel(const unsigned int* __restrict__ p, long long n, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += (unsigned long long)p[i] * (unsigned long long)(i % 1021 + 1);
+    atomicAdd(out, acc);
+}
+constexpr int DBG_SLOTS = 256;
+void dbg_sum(vt_context* c, const void* p, size_t bytes, hipStream_t s) {
+    if (!c->dbg_on || !c->dbg || c->dbg_n >= DBG_SLOTS) return;
+    hipLaunchKernelGGL(dbg_checksum_kernel, dim3(64), dim3(256), 0, s, (const unsigned int*)p, (long long)(bytes / 4), c->dbg + c->dbg_n);
+    ++c->dbg_n;
+}
+
 // y = act(GroupNorm(x)) as bf16 rows.  Uses epilogue-produced partials when present.
 int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int B, int HW, const NormW& n, int groups, int silu, bf16_t* y,
            GnState& g, hipStream_t s, bool out_fp8 = false, bool out_f16 = false /* y holds fp16 bits: the consumer conv runs on fp16 operands */) {
@@ -493,6 +508,8 @@ int run_gn(vt_context* c, const void* x, int xdt /*0 bf16, 1 fp32, 2 fp16*/, int
     if (parts == 0) HIPCK(c, vt_launch_gn_stats(x, xdt, B, HW, n.c, groups, g.partial, &parts, s), "gn_stats");
     g.parts = 0;
     HIPCK(c, vt_launch_gn_finalize(g.partial, parts, B, n.c, groups, 1e-6f, n.g, n.b, g.ss, s, c->status), "gn_finalize");
+    dbg_sum(c, g.partial, (size_t)B * parts * groups * 3 * 4, s);          // (diagnostics: the partials this norm consumed, then its table)
+    dbg_sum(c, g.ss, (size_t)B * n.c * 2 * 4, s);
     if (c->profiling) {
         vt_context::ProfRec r;
         r.e0 = c->next_event(); r.e1 = c->next_event();
@@ -631,6 +648,10 @@ int run_conv(vt_context* c, const ConvW& w, const bf16_t* x, int B, int Hin, int
         if (sc) { h.scX = sc->x; h.scW = x_f16 ? sc->wp16 : sc->wp; h.scCin = sc->cin; h.bias = sc->bias; }
         if (fuse) { h.gn_partial = gn->partial; h.gn_cpg = cpg; gn->parts = vt_conv3x3_halo_tiles(Hin, Win, w.cout, ss ? (xnorm_f32 ? 1 : 2) : 0, c->halo_occ2, sc != nullptr); }
         HIPCK(c, launch_halo(c, h, s), "conv3x3_halo");
+        if (c->dbg_on) {                                           // diagnostics: the conv's stored output (whichever type the stream has)
+            const size_t ne = (size_t)B * Hin * Win * w.cout;
+            if (oh16) dbg_sum(c, oh16, ne * 2, s); else if (o32) dbg_sum(c, o32, ne * 4, s); else if (o16) dbg_sum(c, o16, ne * 2, s);
+        }
         return VT_OK;
     }
     if (ss || sc) return c->fail(VT_ERR_STATE, "internal: fused norm / shortcut requested for a conv the halo kernel cannot run");
@@ -1141,6 +1162,7 @@ int vt_create(int device, vt_context** out) {
 }
 
 void vt_destroy(vt_context* c) {
+    if (c && c->dbg) { DeviceGuard guard(c); (void)hipFree(c->dbg); c->dbg = nullptr; }
     if (!c) return;
     {
         DeviceGuard guard(c);
@@ -1817,6 +1839,24 @@ int vt_resize_u8(vt_context* c, const uint8_t* src_hwc, int src_h, int src_w, in
     unsigned char* tmp = p.tmp ? (unsigned char*)(ws + align_up(ints * 4)) : nullptr;
     HIPCK(c, vt_launch_resize_u8(src_hwc, src_h, src_w, crop_left, crop_top, crop_w, crop_h, dst_hwc, dst_h, dst_w,
                                  p.tab_h ? tab : nullptr, p.kh, p.tab_v ? tab + p.tab_h : nullptr, p.kv, tmp, s), "vt_resize_u8");
+    return VT_OK;
+}
+
+// ---- diagnostics --------------------------------------------------------------------------------
+int vt_debug_trace(vt_context* c, int enable, unsigned long long* sums_out, int max_sums, int* n_out) {
+    if (!c) return VT_ERR_INVALID;
+    DeviceGuard guard(c);
+    if (enable) {
+        if (!c->dbg) HIPCK(c, hipMalloc((void**)&c->dbg, DBG_SLOTS * 8), "hipMalloc(debug trace)");
+        HIPCK(c, hipMemset(c->dbg, 0, DBG_SLOTS * 8), "hipMemset(debug trace)");
+        c->dbg_n = 0; c->dbg_on = true;
+        return VT_OK;
+    }
+    c->dbg_on = false;
+    HIPCK(c, hipDeviceSynchronize(), "hipDeviceSynchronize");
+    const int n = c->dbg_n < max_sums ? c->dbg_n : max_sums;
+    if (sums_out && n > 0) HIPCK(c, hipMemcpy(sums_out, c->dbg, (size_t)n * 8, hipMemcpyDeviceToHost), "hipMemcpy(debug trace)");
+    if (n_out) *n_out = n;
     return VT_OK;
 }
 

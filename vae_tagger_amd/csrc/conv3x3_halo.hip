@@ -21,6 +21,9 @@
 #include "vt_common.h"
 #include "vt_kernels.h"
 
+#ifdef GNIL_DUMP        // diagnostics build only (tests/diagnostics/halo_partials_lane_dump.py)
+extern "C" int vt_debug_gnil_dump(float* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gnil_dump), &buf, sizeof(buf)); }
+#endif
 #ifdef HALO_STAMP
 // Diagnostic build only (tools/stamp_halo.py): wall-clock stamps (s_memrealtime, 100 MHz) of the phases of one workgroup.
 __device__ unsigned long long* g_halo_stamps = nullptr;

@@ -15,7 +15,7 @@ namespace {
 // partials of the output for the first resnet's norm1.
 // packed weight layout: wp[k][cout], k = ci*9 + ky*3 + kx.
 constexpr int CI_PIX = 64, CI_ROWS = 16;
-__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256) VT_NO_PACKED_F32 void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                       const float* __restrict__ bias, float* __restrict__ o32,
                                                       bf16_t* __restrict__ o16, f16_t* __restrict__ oh,
                                                       float* __restrict__ gn_partial,
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) void attn_row_norms_kernel(const bf16_t* __res
 // the same with the fp8 attention's operands as a by-product: q8 | k8 = e4m3(scale q | scale k) (saturated at +-448; a clamp raises
 // status bit 1), and the norms are those of the QUANTISED values -- the Cauchy-Schwarz bound of the exponent shift then holds for
 // the operands the MFMA actually multiplies
-__global__ __launch_bounds__(256) void attn_row_norms_fp8_kernel(const bf16_t* __restrict__ qk, long long rows, int C, float scale,
+__global__ __launch_bounds__(256) VT_NO_PACKED_F32 void attn_row_norms_fp8_kernel(const bf16_t* __restrict__ qk, long long rows, int C, float scale,
                                                                  unsigned char* __restrict__ qk8, float* __restrict__ qn,
                                                                  float* __restrict__ kn, float* __restrict__ sd, int* __restrict__ status) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);

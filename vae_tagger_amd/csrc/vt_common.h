@@ -140,6 +140,25 @@ __device__ __forceinline__ float vt_row16_sum(float x) {
     return x;
 }
 
+// ---- packed fp32 and op_sel: a hazard found in round 4 ----
+// `v_pk_add_f32 d, a, p op_sel:[0,1]` (the HIGH register of the source pair routed into the LOW lane) read 0.0 in lanes 48..63 on
+// some executions when it was the first reader of a register returned by ds_bpermute, even long after the s_waitcnt that
+// covers the return: run to run, one element of one GroupNorm partial computed against pivot 0 (tests/diagnostics/
+// halo_partials_lane_dump.py shows the lane, the element and the missing pivot).  The same code with the pivot in a materialised
+// register pair (no op_sel), or with op_sel_hi:[1,0] (low register into the high lane), is bit-stable over thousands of runs.
+// Rule, enforced by tests/test_isa_lint.py over every kernel of the library: no packed-fp32 instruction with a source op_sel.
+//   - hand-written f32x2 code pins its broadcast operands with VT_PIN_PAIR (an empty asm that makes the pair a real one);
+//   - kernels where the compiler forms packed ops from scalar code carry VT_NO_PACKED_F32.
+// -DGNIL_OP_SEL_PIVOT rebuilds the failing code (tools/build_variant.sh opsel "-DGNIL_OP_SEL_PIVOT"), -DGNIL_DUMP the per-lane dump.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VT_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define VT_NO_PACKED_F32                         // (the host pass of hipcc does not know the feature name)
+#endif
+#define VT_PIN_PAIR(p2) asm volatile("" : "+v"(p2))
+#ifdef GNIL_DUMP
+static __device__ float* g_gnil_dump = nullptr;     // diagnostics build only: per-lane (s, ss, pivot, v[q][0][0]) before the lane reduction
+#endif
 // Variant for the "interleaved" cout map of conv3x3_halo: a lane's registers hold 16 CONSECUTIVE couts of its pixel,
 // cout = wave_cout0 + 16*fq + 4*i + r (tile i, register r), so every GroupNorm group (4, 8 or 16 channels) lives in
 // ONE lane; only the 16 pixel columns (fr) are merged across lanes.
@@ -175,7 +194,10 @@ __device__ __forceinline__ void vt_gn_epilogue_partials_il(const f32x4 (&v)[TC][
         for (int q = 0; q < NG; ++q) piv[q] = __shfl(v[q * TPG][0][0], lane & 48, 64);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            const f32x2 p2 = {piv[q], piv[q]};
+            f32x2 p2 = {piv[q], piv[q]};
+#ifndef GNIL_OP_SEL_PIVOT
+            VT_PIN_PAIR(p2);                           // without it the compiler routes piv[q] into the packed ops by op_sel: see above
+#endif
             f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};    // two accumulators per sum: packed adds / fmas (v_pk_add_f32, v_pk_fma_f32)
 #pragma unroll
             for (int i = q * TPG; i < (q + 1) * TPG; ++i) {
@@ -189,6 +211,12 @@ __device__ __forceinline__ void vt_gn_epilogue_partials_il(const f32x4 (&v)[TC][
                 }
             }
             s[q] = s2[0] + s2[1]; ss[q] = q2[0] + q2[1];
+#ifdef GNIL_DUMP
+            if (g_gnil_dump) {
+                float* dd = g_gnil_dump + (((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4 + q) * 4;
+                dd[0] = s[q]; dd[1] = ss[q]; dd[2] = piv[q]; dd[3] = v[q * TPG][0][0];
+            }
+#endif
         }
 #pragma unroll
         for (int q = 0; q < NG; ++q) { s[q] = vt_row16_sum(s[q]); ss[q] = vt_row16_sum(ss[q]); }
