@@ -253,6 +253,7 @@ def main():
     dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(a.tags), seed=1), strict=False)
     dec = dec.to(dev).eval()
     pipe = EncodeTagPipeline(vae_model, dec)
+    pipe.check_finite = False                 # no host synchronise inside the timed steps: the word is read once after them
     _quiet.__exit__(None, None, None)
     if a.generic_conv:
         pipe.ctx.call("vt_set_flag", 0, 0)

@@ -326,6 +326,14 @@ def test_fp16_overflow_trips_the_status_word_and_fp32_storage_matches_oracle():
     m.check_finite = True                                      # the same switch on the diffusers-shaped object
     with pytest.raises(FloatingPointError):
         w.encode(x.cuda())
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+    pipe = EncodeTagPipeline(w, _decoder(11))                  # the fused pipeline checks by default too (round 4): no silent non-finite tags
+    with pytest.raises(FloatingPointError):
+        pipe.tag(x.cuda())
+    assert pipe.status() == 0
+    pipe.check_finite = False                                  # ... unless the caller polls the word itself (the CLIs, bench.py)
+    _, lat_p = pipe.logits(x.cuda(), return_latent=True)       # (the TAGS of non-finite latents can look perfectly finite: only the word tells)
+    assert pipe.status() == 1 and pipe.status() == 0 and not torch.isfinite(lat_p).all()
     m.set_fp32_residual(True)
     lat32 = w.encode(x.cuda())                                 # check_finite still on: no raise
     assert m.status() == 0

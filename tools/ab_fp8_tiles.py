@@ -23,6 +23,7 @@ with contextlib.redirect_stdout(sys.stderr):
     dec = create_attention_decoder(16, H // 8, W // 8, N, {"use_spatial_attention": True, "use_self_attention": True})
     dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(N), seed=1), strict=False)
     pipe = EncodeTagPipeline(vm, dec.to("cuda").eval())
+    pipe.check_finite = False
 pipe.set_fp8(True)
 x = synth.synth_images(B, H, W, seed=1000).cuda()
 ctx = pipe.ctx

@@ -88,6 +88,7 @@ try:
         dec = create_attention_decoder(16, a.res // 8, a.res // 8, a.tags, {"use_spatial_attention": True, "use_self_attention": True})
         dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(a.tags), seed=1), strict=False)
         pipe = EncodeTagPipeline(vm, dec.to("cuda").eval())
+        pipe.check_finite = False
     if a.fp8: pipe.set_fp8(True)
     x = synth.synth_images(a.batch, a.res, a.res, seed=1000).cuda()
     for _ in range(3): pipe.logits(x)

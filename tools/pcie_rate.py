@@ -13,6 +13,7 @@ with contextlib.redirect_stdout(sys.stderr):
     dec = create_attention_decoder(16, 128, 128, 10000, {"use_spatial_attention": True, "use_self_attention": True})
     dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(10000), seed=1), strict=False)
     pipe = EncodeTagPipeline(DiffusersVAEWrapper(vae).to("cuda").eval(), dec.to("cuda").eval())
+    pipe.check_finite = False
 B = 16
 x32 = synth.synth_images(B, 1024, 1024, seed=1000)
 u8 = ((x32.permute(0, 2, 3, 1) * 0.5 + 0.5) * 255).round().to(torch.uint8).contiguous()

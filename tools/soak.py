@@ -15,6 +15,7 @@ vae_model = DiffusersVAEWrapper(vae).to("cuda").eval()
 dec = create_attention_decoder(16, 128, 128, 1000, {"use_spatial_attention": True, "use_self_attention": True})
 dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(1000), seed=1), strict=False)
 pipe = EncodeTagPipeline(vae_model, dec.to("cuda").eval())
+pipe.check_finite = False
 for fv in sys.argv[3:]:
     f, v = fv.split("=")
     pipe.ctx.call("vt_set_flag", int(f), int(v))

@@ -19,6 +19,7 @@ with contextlib.redirect_stdout(sys.stderr):
     dec = create_attention_decoder(16, 128, 128, 1000, {"use_spatial_attention": True, "use_self_attention": True})
     dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(1000), seed=1), strict=False)
     pipe = EncodeTagPipeline(vm, dec.to(dev).eval())
+    pipe.check_finite = False
 L = pipe.ctx.lib
 L.vt_debug_halo_stamps_nth.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]; L.vt_debug_halo_stamps_nth.restype = ctypes.c_int
 x = synth.synth_images(16, 1024, 1024, seed=1000).to(dev)

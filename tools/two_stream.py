@@ -18,6 +18,7 @@ with contextlib.redirect_stdout(sys.stderr):
     dec = create_attention_decoder(16, 128, 128, 10000, {"use_spatial_attention": True, "use_self_attention": True})
     dec.load_state_dict(synth.synth_state_dict(synth.attention_decoder_manifest(10000), seed=1), strict=False)
     pipe = EncodeTagPipeline(DiffusersVAEWrapper(vae).to(dev).eval(), dec.to(dev).eval())
+    pipe.check_finite = False
 for fv in sys.argv[3:]:
     f, v = fv.split("=")
     pipe.ctx.call("vt_set_flag", int(f), int(v))

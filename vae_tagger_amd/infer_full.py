@@ -323,6 +323,7 @@ def infer_and_classify(args):
     lo, hi = sharding.shard_range(len(image_paths), rank, world)
     my_paths = image_paths[lo:hi]
     pipe = EncodeTagPipeline(vae_model, decoder)
+    pipe.check_finite = False                 # the batches' health words are read in stream order (status_async), one batch late
     f16 = bool(getattr(args, "fp16_operands", False)) and not getattr(args, "fp8", False)
     if f16:
         pipe.set_fp16_operands(True)

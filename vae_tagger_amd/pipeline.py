@@ -14,6 +14,13 @@ from .modules import _HipDecoder, smart_crop_box
 
 
 class EncodeTagPipeline:
+    # vt_encode_tag never synchronises the host: a residual stream that left the fp16 range of its storage, or (fp8 mode) an activation that was
+    # clamped to the e4m3 range, only raises the context's sticky word (vt_status).  Like the reference-shaped wrapper
+    # (DiffusersVAEWrapper.check_finite), the pipeline reads the word after every logits() / tag() -- one 4-byte copy and a stream synchronise -- and
+    # raises, so no caller gets non-finite or clamped tags silently.  Callers that synchronise elsewhere and poll the word themselves (the pipelined
+    # CLIs through status_async, bench.py, tools/) set check_finite = False.
+    check_finite = True
+
     def __init__(self, vae_model, decoder, device=None):
         vae = vae_model.vae if isinstance(vae_model, DiffusersVAEWrapper) else vae_model
         if not isinstance(vae, AutoencoderKL) or not isinstance(decoder, _HipDecoder):
@@ -51,7 +58,18 @@ class EncodeTagPipeline:
         ws, ptr = workspace(self.device, need)
         self.ctx.call("vt_encode_tag", vp(x), B, H, W, vp(lat), vp(out), ctypes.c_void_p(ptr), need,
                       stream_ptr(self.device))
+        if self.check_finite:
+            self.raise_on_status()
         return (out, lat) if return_latent else out
+
+    def raise_on_status(self):
+        """Read (and clear) the sticky health word -- synchronises -- and raise what it says."""
+        st = self.status()
+        if st & _lib.VT_STATUS_NONFINITE:
+            raise FloatingPointError("non-finite activations in the encoder: the fp16 residual-stream storage overflowed "
+                                     "(vt_set_flag(ctx, 4, 0) stores it as fp32) or the input / checkpoint holds inf / NaN")
+        if st & _lib.VT_STATUS_FP8_SATURATED:
+            raise FloatingPointError("fp8 mode: activations exceeded the e4m3 range and were clamped (set_fp8(False) returns to the bf16 path)")
 
     @torch.no_grad()
     def confidence(self, logits):
