@@ -1,4 +1,4 @@
-"""Which input shapes make the (default) encoder non-deterministic?   python tests/diagnostics/nondeterminism_shapes.py [reps]"""
+"""Which input shapes make the encoder non-deterministic?   python tests/diagnostics/nondeterminism_shapes.py [reps] [bf16|fp8|f16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import contextlib, torch
@@ -9,6 +9,10 @@ with contextlib.redirect_stdout(sys.stderr):
     vae = load_diffusers_vae_from_config(get_diffusers_vae_config())
     vae.load_state_dict(synth.synth_state_dict(synth.encoder_manifest(), seed=0), strict=False)
     vm = DiffusersVAEWrapper(vae).to("cuda").eval(); vm.check_finite = False
+mode = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+if mode == "fp8": vae._context().call("vt_set_flag", 11, 1)
+if mode == "f16": vae._context().call("vt_set_flag", 18, 1)
+print(f"mode {mode}", flush=True)
 for (B, h, w) in ((2, 264, 136), (1, 264, 136), (2, 264, 128), (2, 256, 136), (2, 136, 264), (2, 200, 104), (2, 520, 264), (2, 248, 120), (4, 264, 136), (2, 72, 88), (2, 100, 76), (2, 328, 200)):
     x = synth.synth_images(B, h, w, seed=h + 2 * w).cuda()
     ref = vm.encode(x).clone(); bad = 0; worst = 0.0; imgs = set()
