@@ -128,9 +128,9 @@ def test_mfma_kernels_keep_two_waves_per_simd_without_spilling(budget_asm, name)
         assert int(b["vgpr_spill_count"]) <= max_spill and int(b["sgpr_spill_count"]) == 0, (k, b["vgpr_spill_count"], b["sgpr_spill_count"])
 
 
-# ---- round 4: packed fp32 with a source op_sel.  `v_pk_add_f32 d, a, p op_sel:[0,1]` (the HIGH register of a pair routed into the LOW lane) read
-# 0.0 in lanes 48..63 on some executions when it was the first reader of a ds_bpermute result: one element of one GroupNorm partial summed against
-# pivot 0, so ragged shapes encoded differently run to run (vt_common.h, VT_PIN_PAIR / VT_NO_PACKED_F32).  No kernel of the BUILT
+# ---- round 4: packed fp32 with a source op_sel.  In the halo conv kernels `v_pk_add_f32 d, a, p op_sel:[0,1]` (the HIGH register of a pair routed into
+# the LOW lane) sometimes read 0.0 instead in lanes 48..63: one element of one GroupNorm partial summed against the wrong pivot, so
+# ragged shapes encoded differently run to run (vt_common.h, VT_PIN_PAIR / VT_NO_PACKED_F32).  No kernel of the BUILT
 # library may contain such an instruction (op_sel_hi -- low register into the high lane -- is what the compiler emits for pinned pairs, and is stable).
 def test_no_packed_fp32_instruction_routes_a_source_by_op_sel(tmp_path):
     from vae_tagger_amd import _lib

@@ -141,15 +141,16 @@ __device__ __forceinline__ float vt_row16_sum(float x) {
 }
 
 // ---- packed fp32 and op_sel: a hazard found in round 4 ----
-// `v_pk_add_f32 d, a, p op_sel:[0,1]` (the HIGH register of the source pair routed into the LOW lane) read 0.0 in lanes 48..63 on
-// some executions when it was the first reader of a register returned by ds_bpermute, even long after the s_waitcnt that
-// covers the return: run to run, one element of one GroupNorm partial computed against pivot 0 (tests/diagnostics/
-// halo_partials_lane_dump.py shows the lane, the element and the missing pivot).  The same code with the pivot in a materialised
-// register pair (no op_sel), or with op_sel_hi:[1,0] (low register into the high lane), is bit-stable over thousands of runs.
-// Rule, enforced by tests/test_isa_lint.py over every kernel of the library: no packed-fp32 instruction with a source op_sel.
+// In the halo conv kernels `v_pk_add_f32 d, a, v[p-1:p] op_sel:[0,1]` (the HIGH register of the source pair routed into the LOW lane) sometimes
+// computed its low lane with 0.0 in place of that register -- in lanes 48..63, load dependent (never at batch 1, every launch at batch 4), whatever wrote
+// the pair (ds_bpermute or v_readlane) and however long before: run to run, one element of one GroupNorm partial was summed against the wrong
+// pivot (tests/diagnostics/halo_partials_lane_dump.py shows the lane and the element; -DGNIL_ASM_MODE=1..4 place the instruction by hand: modes 1-3
+// differ in 300 of 300 launches, the mirrored op_sel_hi:[1,0] form in none).  The same code with the pivot in a materialised register pair is
+// bit-stable over thousands of launches.  Rule, enforced by tests/test_isa_lint.py over every kernel of the BUILT library: no packed-fp32 instruction
+// with a source op_sel.
 //   - hand-written f32x2 code pins its broadcast operands with VT_PIN_PAIR (an empty asm that makes the pair a real one);
 //   - kernels where the compiler forms packed ops from scalar code carry VT_NO_PACKED_F32.
-// -DGNIL_OP_SEL_PIVOT rebuilds the failing code (tools/build_variant.sh opsel "-DGNIL_OP_SEL_PIVOT"), -DGNIL_DUMP the per-lane dump.
+// -DGNIL_OP_SEL_PIVOT rebuilds the round-3 code (tools/build_variant.sh opsel "-DGNIL_OP_SEL_PIVOT"), -DGNIL_DUMP the per-lane dump.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define VT_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
 #else
@@ -191,9 +192,37 @@ __device__ __forceinline__ void vt_gn_epilogue_partials_il(const f32x4 (&v)[TC][
         constexpr int NG = TC / TPG;
         float piv[NG], s[NG], ss[NG];
 #pragma unroll
-        for (int q = 0; q < NG; ++q) piv[q] = __shfl(v[q * TPG][0][0], lane & 48, 64);
+        for (int q = 0; q < NG; ++q) {
+#if defined(GNIL_ASM_MODE) && GNIL_ASM_MODE == 3    // experiment: the pivot never passes through the LDS
+            const int x0 = __builtin_bit_cast(int, v[q * TPG][0][0]);
+            const int r0 = __builtin_amdgcn_readlane(x0, 0), r1 = __builtin_amdgcn_readlane(x0, 16), r2 = __builtin_amdgcn_readlane(x0, 32),
+                      r3 = __builtin_amdgcn_readlane(x0, 48);
+            piv[q] = __builtin_bit_cast(float, fq == 0 ? r0 : fq == 1 ? r1 : fq == 2 ? r2 : r3);
+#else
+            piv[q] = __shfl(v[q * TPG][0][0], lane & 48, 64);
+#endif
+        }
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
+#ifdef GNIL_ASM_MODE
+            // experiments on the hazard of section 4.14 inside the kernel that shows it: the FIRST subtract of each group is a hand-placed packed add
+            // whose pivot operand is read first by this instruction; everything after it uses the pinned pair.  Modes: 1 = op_sel:[0,1], pivot in the
+            // high half; 2 = the same after s_waitcnt lgkmcnt(0) and 16 idle cycles; 3 = mode 1 with a v_readlane pivot; 4 = op_sel_hi:[1,0], pivot
+            // in the low half (control); 5 = mode 1 with 1000.0 instead of 0.0 in the low half (what does a wrong lane read: the low register, or zero?).
+            f32x2 pr = GNIL_ASM_MODE == 4 ? f32x2{piv[q], 0.f} : f32x2{GNIL_ASM_MODE == 5 ? 1000.f : 0.f, piv[q]};     // mode 5: a sentinel in the low half
+            const f32x2 a01 = {v[q * TPG][0][0], v[q * TPG][0][1]};
+            f32x2 d_first;
+#if GNIL_ASM_MODE == 2
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(pr));
+#endif
+#if GNIL_ASM_MODE == 4
+            asm volatile("v_pk_add_f32 %0, %2, %1 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(d_first), "+v"(pr) : "v"(a01));
+            piv[q] = pr[0];
+#else
+            asm volatile("v_pk_add_f32 %0, %2, %1 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(d_first), "+v"(pr) : "v"(a01));
+            piv[q] = pr[1];
+#endif
+#endif
             f32x2 p2 = {piv[q], piv[q]};
 #ifndef GNIL_OP_SEL_PIVOT
             VT_PIN_PAIR(p2);                           // without it the compiler routes piv[q] into the packed ops by op_sel: see above
@@ -204,7 +233,11 @@ __device__ __forceinline__ void vt_gn_epilogue_partials_il(const f32x4 (&v)[TC][
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
                     if (FULL || ((valid >> j) & 1u)) {
-                        const f32x2 d0 = f32x2{v[i][j][0], v[i][j][1]} - p2, d1 = f32x2{v[i][j][2], v[i][j][3]} - p2;
+                        f32x2 d0 = f32x2{v[i][j][0], v[i][j][1]} - p2;
+                        const f32x2 d1 = f32x2{v[i][j][2], v[i][j][3]} - p2;
+#ifdef GNIL_ASM_MODE
+                        if (i == q * TPG && j == 0) d0 = d_first;
+#endif
                         s2 += d0; q2 += d0 * d0;
                         s2 += d1; q2 += d1 * d1;
                     }
