@@ -60,6 +60,9 @@ int vt_decoder_finalize(vt_context* ctx);
  *                         0: moments [B,2*latent,H/8,W/8] (mean | logvar) -- AutoencoderKL.encode surface
  *                         1: latent_dist.mode() = mean [B,latent,H/8,W/8]
  *                         2: mode() * scaling_factor + shift_factor -- DiffusersVAEWrapper.encode
+ *                       (H/8, W/8 for the four-block FLUX configuration; in general H >> (num_blocks - 1), W >> (num_blocks - 1):
+ *                       one Downsample2D per block but the last.  The library cannot see the size of latent_out: the caller's
+ *                       buffer must hold B x channels x that many fp32 values.)
  * vt_decode_logits   <- decoder.forward(latent), modules.py:424-468 / :333-349 -> fp32 [B,N]
  * vt_get_confidence  <- sigmoid + descending sort, modules.py:470-475 (ties: ascending tag index; NaN logits sort last;
  *                       any N: up to 16384 tags in one LDS pass, more through global-memory merge passes)
