@@ -1072,3 +1072,50 @@ def test_encoder_is_bit_stable_run_to_run_on_ragged_shapes(vae, mode):
         ctx.call("vt_set_flag", 11, 0)
         ctx.call("vt_set_flag", 18, 0)
         vae.check_finite = old_check
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp8", "fp16_operands"])
+def test_c_abi_writes_stay_inside_the_buffers_it_was_given(vae, mode):
+    """vt_encode_tag through the C ABI with guard bands: the workspace is exactly vt_encode_tag_workspace_bytes() long and the latent / logit buffers
+    exactly their documented sizes (include/vae_tagger_hip.h), each followed by 1 MB of a byte pattern that must survive the call -- on tile-aligned,
+    ragged and odd shapes, in every numeric mode.  (Round 4: a test that passed an 8 x 8 latent buffer for a 32 x 32 latent went unnoticed for rounds;
+    this is the same check pointed at the library's own planner, which grew this round: to_out's partials, planar and fp16 operand copies.)"""
+    import ctypes
+    from vae_tagger_amd.pipeline import EncodeTagPipeline
+    n = 37
+    pipe = EncodeTagPipeline(vae, _decoder(n))
+    pipe.check_finite = False
+    ctx, L = pipe.ctx, pipe.ctx.lib
+    GUARD, PAT = 1 << 20, 0xA5
+    try:
+        if mode == "fp8":
+            pipe.set_fp8(True)
+        if mode == "fp16_operands":
+            ctx.call("vt_set_flag", 18, 1)
+        for (b, hh, ww) in ((2, 128, 192), (3, 264, 136), (1, 100, 76), (2, 72, 88), (1, 512, 512)):
+            x = synth.synth_images(b, hh, ww, seed=hh + ww).cuda()
+            need = L.vt_encode_tag_workspace_bytes(ctx.handle, b, hh, ww)
+            assert need > 0
+            n_lat, n_log = b * 16 * (hh // 8) * (ww // 8) * 4, b * n * 4
+            bufs = []
+            for nbytes in (need, n_lat, n_log):
+                t = torch.full((nbytes + 256 + GUARD,), PAT, dtype=torch.uint8, device="cuda")
+                p = (t.data_ptr() + 255) // 256 * 256
+                bufs.append((t, p, p - t.data_ptr()))
+            (tw, pw, ow), (tl, pl, ol), (tg, pg, og) = bufs
+            rc = L.vt_encode_tag(ctx.handle, ctypes.c_void_p(x.data_ptr()), b, hh, ww, ctypes.c_void_p(pl), ctypes.c_void_p(pg), ctypes.c_void_p(pw), need, None)
+            assert rc == 0, L.vt_last_error(ctx.handle)
+            torch.cuda.synchronize()
+            for what, (t, p, off), nbytes in (("workspace", bufs[0], need), ("latent", bufs[1], n_lat), ("logits", bufs[2], n_log)):
+                tail = t[off + nbytes:]
+                assert bool((tail == PAT).all()), (mode, b, hh, ww, what, int((tail != PAT).nonzero()[0]))
+                assert bool((t[:off] == PAT).all()), (mode, b, hh, ww, what, "bytes in front of the buffer")
+            lat = tl[ol:ol + n_lat].view(torch.float32).view(b, 16, hh // 8, ww // 8)
+            lg = tg[og:og + n_log].view(torch.float32).view(b, n)
+            assert torch.isfinite(lat).all() and torch.isfinite(lg).all()
+            ref_lg, ref_lat = pipe.logits(x, return_latent=True)                      # the Python mirror allocates by its own rule: same bits
+            assert torch.equal(ref_lg, lg) and torch.equal(ref_lat, lat)
+        assert pipe.status() == 0
+    finally:
+        pipe.set_fp8(False)
+        ctx.call("vt_set_flag", 18, 0)
