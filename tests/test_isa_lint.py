@@ -131,7 +131,8 @@ def test_mfma_kernels_keep_two_waves_per_simd_without_spilling(budget_asm, name)
 # ---- round 4: packed fp32 with a source op_sel.  In the halo conv kernels `v_pk_add_f32 d, a, p op_sel:[0,1]` (the HIGH register of a pair routed into
 # the LOW lane) sometimes read 0.0 instead in lanes 48..63: one element of one GroupNorm partial summed against the wrong pivot, so
 # ragged shapes encoded differently run to run (vt_common.h, VT_PIN_PAIR / VT_NO_PACKED_F32).  No kernel of the BUILT
-# library may contain such an instruction (op_sel_hi -- low register into the high lane -- is what the compiler emits for pinned pairs, and is stable).
+# library may contain such an instruction (op_sel_hi -- low register into the high lane -- is what the compiler emits for pinned pairs, and is stable);
+# v_pk_mov_b32, the pair shuffle the compiler builds such operands with, is held to the same rule (gn_apply_f32in_kernel).
 def test_no_packed_fp32_instruction_routes_a_source_by_op_sel(tmp_path):
     from vae_tagger_amd import _lib
     objdump = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin", "llvm-objdump")
@@ -150,7 +151,7 @@ def test_no_packed_fp32_instruction_routes_a_source_by_op_sel(tmp_path):
             m = re.match(r"^[0-9a-f]+ <(\w+)>:", l)
             if m:
                 kernel = m.group(1)
-            elif re.search(r"\bv_pk_(add|mul|fma)_f32\b", l):
+            elif re.search(r"\bv_pk_(add_f32|mul_f32|fma_f32|mov_b32)\b", l):      # every VOP3P instruction on 64-bit register pairs
                 packed += 1
                 if re.search(r"op_sel:\[", l):
                     bad += 1; offenders.add(kernel)

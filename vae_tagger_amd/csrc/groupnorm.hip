@@ -5,6 +5,8 @@
 //   finalize : deterministic fixed-order merge in fp64 -> per (image, channel) (scale, shift)
 //   apply    : y = act(x*scale + shift), one read of x, one bf16 write (the MFMA operand of the next conv)
 // x is the fp32 residual stream or a bf16 conv output.  16-B vector accesses, 8 channels per lane.
+#include <type_traits>
+
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -210,10 +212,8 @@ __global__ __launch_bounds__(FIN_T) void gn_finalize_kernel(const float* __restr
 // write; 16 channels per lane with 16-B stores 3.8 TB/s; lane pairs exchanging through DPP so that half the lanes, or -- with two
 // pixels per lane -- all lanes store 16 B: 4.4 TB/s and 1 % slower end to end; plain instead of nontemporal stores -0.5 %).
 template <typename T, bool SILU, int OUT>
-__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x,
-                                                              const float* __restrict__ scale_shift,
-                                                              void* __restrict__ yv, int HW, int C,
-                                                              int pix_per_block, float out_scale, int* __restrict__ status) {
+__device__ __forceinline__ void gn_apply_body(const T* __restrict__ x, const float* __restrict__ scale_shift, void* __restrict__ yv, int HW, int C,
+                                              int pix_per_block, float out_scale, int* __restrict__ status) {
     constexpr int CPL = 8;
     constexpr bool OUT8 = OUT == 1;
     const int b = blockIdx.y;
@@ -279,6 +279,29 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     if (OUT8 && status && amax > 448.f) atomicOr(status, 2);
 }
 
+template <typename T, bool SILU, int OUT>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift, void* __restrict__ yv, int HW,
+                                                              int C, int pix_per_block, float out_scale, int* __restrict__ status) {
+    gn_apply_body<T, SILU, OUT>(x, scale_shift, yv, HW, C, pix_per_block, out_scale, status);
+}
+// fp32 input (the fp32 residual-stream storage of vt_set_flag(ctx, 4, 0)): the compiler gathers the (scale, shift) pairs of this instantiation with
+// v_pk_mov_b32 ... op_sel:[1,0] -- a high register routed into the low lane, the operand form of the hazard in DESIGN.md 4.14 -- so this cold variant is
+// built without packed fp32 (tests/test_isa_lint.py forbids the form in every kernel).
+template <typename T, bool SILU, int OUT>
+__global__ __launch_bounds__(GN_THREADS) VT_NO_PACKED_F32 void gn_apply_f32in_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift,
+                                                                                     void* __restrict__ yv, int HW, int C, int pix_per_block, float out_scale,
+                                                                                     int* __restrict__ status) {
+    gn_apply_body<T, SILU, OUT>(x, scale_shift, yv, HW, C, pix_per_block, out_scale, status);
+}
+
+template <typename T, bool SILU, int OUT>
+void launch_gn_apply(dim3 grid, dim3 block, hipStream_t s, const T* x, const float* scale_shift, void* y, int HW, int C, int ppb, float out_scale, int* status) {
+    if constexpr (std::is_same<T, float>::value)
+        hipLaunchKernelGGL((gn_apply_f32in_kernel<T, SILU, OUT>), grid, block, 0, s, x, scale_shift, y, HW, C, ppb, out_scale, status);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<T, SILU, OUT>), grid, block, 0, s, x, scale_shift, y, HW, C, ppb, out_scale, status);
+}
+
 bool gn_shape_ok(int C, int groups) {
     if (C <= 0 || groups <= 0 || C % groups) return false;
     const int cpg = C / groups;
@@ -342,7 +365,7 @@ hipError_t vt_launch_gn_apply(const void* x, int x_dtype, const float* scale_shi
 #endif
     const int ppb = ppp * (out_fp8_scale > 0.f ? 2 * GN_PASSES : GN_PASSES);   // pixels per block: short blocks stream faster (bf16: 5.3 -> 5.9 TB/s at 4 passes; fp8 output: 8 passes +0.6 % images/s)
     dim3 grid((HW + ppb - 1) / ppb, B), block(GN_THREADS);
-#define GN_APPLY(T, A, O) hipLaunchKernelGGL((gn_apply_kernel<T, A, O>), grid, block, 0, s, (const T*)x, scale_shift, y, HW, C, ppb, out_fp8_scale, status)
+#define GN_APPLY(T, A, O) launch_gn_apply<T, A, O>(grid, block, s, (const T*)x, scale_shift, y, HW, C, ppb, out_fp8_scale, status)
 #define GN_APPLY2(T) do { if (silu) { if (o8) GN_APPLY(T, true, 1); else if (out_f16) GN_APPLY(T, true, 2); else GN_APPLY(T, true, 0); } \
                           else { if (o8) GN_APPLY(T, false, 1); else if (out_f16) GN_APPLY(T, false, 2); else GN_APPLY(T, false, 0); } } while (0)
     if (x_dtype == 1) GN_APPLY2(float);
