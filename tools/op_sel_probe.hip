@@ -51,12 +51,20 @@ __global__ __launch_bounds__(256, 2) void probe(int iters, unsigned* nbad, Rec* 
     for (int phase = 0; phase < PHASES; ++phase) {
         if ((phase + start) & 1) {
             for (int it = 0; it < per; ++it) {
-                if (NEIGH != 1) {                 // the neighbour's main loop: MFMAs fed by ds_read_b128
+                if (NEIGH == 3) {                 // a dense main loop: 32 MFMAs back to back at raised priority, operands fetched once per 32 (the conv kernel's K-step)
+                    const bf16x8 a = *(const bf16x8*)(lds + ((it * 64 + lane) * 4 & 8188)), b = *(const bf16x8*)(lds + (((it + 7) * 64 + lane) * 4 & 8188));
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                } else if (NEIGH != 1) {          // the neighbour's main loop: MFMAs fed by ds_read_b128
                     const bf16x8 a = *(const bf16x8*)(lds + ((it * 64 + lane) * 4 & 8188)), b = *(const bf16x8*)(lds + (((it + 7) * 64 + lane) * 4 & 8188));
 #pragma unroll
                     for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
                 }
-                if (NEIGH != 0) {                 // the neighbour's epilogue: DPP row sums (quad_perm, row_half_mirror, row_mirror, bound_ctrl) as in vt_row16_sum
+                if (NEIGH == 1 || NEIGH == 2) {    // the neighbour's epilogue: DPP row sums (quad_perm, row_half_mirror, row_mirror, bound_ctrl) as in vt_row16_sum
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         float x = acc[i][1] + (float)it;
@@ -141,7 +149,7 @@ void run(const char* what, int iters) {
     unsigned h[2]; Rec r[16];
     CHECK(hipMemcpy(h, nbad, 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(r, recs, sizeof(r), hipMemcpyDeviceToHost));
     const double checks = (double)nblk * 4 * 64 * 2 * (iters / 2);
-    printf("pair " RPAIR " neighbour %s %-64s gap %d: %u wrong of %.3g half-results (%.1f ms)\n", NEIGH == 0 ? "MFMA" : NEIGH == 1 ? "DPP " : "MFMA+DPP", what, GAP, h[0], checks, ms);
+    printf("pair " RPAIR " neighbour %s %-64s gap %d: %u wrong of %.3g half-results (%.1f ms)\n", NEIGH == 0 ? "MFMA" : NEIGH == 1 ? "DPP " : NEIGH == 2 ? "MFMA+DPP" : "dense MFMA", what, GAP, h[0], checks, ms);
     for (unsigned i = 0; i < h[1] && i < 6; ++i)
         printf("      block %d iteration %d lane %d half %d: want %g got %g\n", r[i].blk, r[i].iter, r[i].lane, r[i].half, r[i].want, r[i].got);
     CHECK(hipFree(nbad)); CHECK(hipFree(recs)); CHECK(hipFree(sink));
@@ -160,6 +168,9 @@ int main(int argc, char** argv) {
         run<3, 0, 1>("op_sel:[0,1], pivot by v_mov_b32 (no LDS), 0.0 in the low register", iters);
         run<3, 0, 2>("op_sel:[0,1], pivot by v_mov_b32 (no LDS), 0.0 in the low register", iters);
         run<1, 0, 2>("op_sel_hi:[1,0] (low register -> high lane), ds_bpermute pivot", iters);
+        run<3, 0, 3>("op_sel:[0,1], pivot by v_mov_b32 (no LDS), 0.0 in the low register", iters / 4);
+        run<0, 0, 3>("op_sel:[0,1] (high register -> low lane), ds_bpermute pivot", iters / 4);
+        run<1, 0, 3>("op_sel_hi:[1,0] (low register -> high lane), ds_bpermute pivot", iters / 4);
     }
     return 0;
 }

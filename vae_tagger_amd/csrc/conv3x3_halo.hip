@@ -73,6 +73,10 @@ __device__ __forceinline__ f32x4 halo_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
 #else
     constexpr bool H = F16;
 #endif
+#ifdef GNIL_NO_MFMA          // experiment: the main loop without its matrix instructions (results are wrong by design)
+    asm volatile("" :: "v"(a), "v"(b));
+    return c;
+#endif
     if constexpr (H) {
         typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -234,7 +238,11 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
             const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
             const bool v = hr < HROWS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             const void* src = v ? (const void*)(Xb + ((iy * a.W + ix) * a.Cin + dchunk * 8 + chunk * 32)) : a.zeros;
+#ifndef GNIL_NO_DMA          // experiment: the main loop without its LDS-DMA (results are wrong by design)
             __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(src), VT_LDS_PTR(dst + (j * NLD + wave) * 1024), 16, 0, 0);
+#else
+            asm volatile("" :: "v"(src));
+#endif
             hr += NLD * 16;                                         // next piece: NLD*16 halo rows further
             hx += (NLD * 16) % HWID; hy += (NLD * 16) / HWID;
             if (hx >= HWID) { hx -= HWID; ++hy; }
@@ -257,7 +265,11 @@ void conv3x3_halo_kernel(const Conv3x3Args a) {
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
             if (WPCS % NLD == 0 || j * NLD + wave < WPCS)
+#ifndef GNIL_NO_DMA
                 __builtin_amdgcn_global_load_lds(VT_GLOBAL_PTR(wt + j * NLD * 16 * 32), VT_LDS_PTR(dst + (j * NLD + wave) * 1024), 16, 0, 0);
+#else
+                asm volatile("" :: "v"(wt));
+#endif
     };
     // register-staged row: 8 channels of one halo pixel (XT 1: 2 x 16 B of fp32, XT 2: 16 B of bf16)
     auto load_row = [&](int j, int chunk, f32x4& r0, f32x4& r1) {
@@ -756,7 +768,11 @@ hipError_t launch(const Conv3x3Args& a, hipStream_t s) {
         }
     }
 #endif
+#ifdef GNIL_ONE_WG           // experiment: more LDS than half a CU has, so that workgroups never share a CU
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NWV), smem > 90 * 1024 ? smem : 90 * 1024, s, k);
+#else
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NWV), smem, s, k);
+#endif
     return hipGetLastError();
 }
 
