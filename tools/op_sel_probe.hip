@@ -51,7 +51,23 @@ __global__ __launch_bounds__(256, 2) void probe(int iters, unsigned* nbad, Rec* 
     for (int phase = 0; phase < PHASES; ++phase) {
         if ((phase + start) & 1) {
             for (int it = 0; it < per; ++it) {
-                if (NEIGH == 3) {                 // a dense main loop: 32 MFMAs back to back at raised priority, operands fetched once per 32 (the conv kernel's K-step)
+                if (NEIGH == 4) {                 // dense MFMAs whose A / B operands live in v[132:135] / v[136:139] -- the registers the conv kernel keeps its fragments in, and the pair under test
+                    const bf16x8 a = *(const bf16x8*)(lds + ((it * 64 + lane) * 4 & 8188)), b = *(const bf16x8*)(lds + (((it + 7) * 64 + lane) * 4 & 8188));
+                    __builtin_amdgcn_s_setprio(1);
+                    asm volatile("v_mov_b32 v132, %8\n\tv_mov_b32 v133, %9\n\tv_mov_b32 v134, %10\n\tv_mov_b32 v135, %11\n\t"
+                                 "v_mov_b32 v136, %12\n\tv_mov_b32 v137, %13\n\tv_mov_b32 v138, %14\n\tv_mov_b32 v139, %15\n\t"
+                                 ".rept 4\n\t"
+                                 "v_mfma_f32_16x16x32_bf16 %0, v[132:135], v[136:139], %0\n\tv_mfma_f32_16x16x32_bf16 %1, v[132:135], v[136:139], %1\n\t"
+                                 "v_mfma_f32_16x16x32_bf16 %2, v[132:135], v[136:139], %2\n\tv_mfma_f32_16x16x32_bf16 %3, v[132:135], v[136:139], %3\n\t"
+                                 "v_mfma_f32_16x16x32_bf16 %4, v[132:135], v[136:139], %4\n\tv_mfma_f32_16x16x32_bf16 %5, v[132:135], v[136:139], %5\n\t"
+                                 "v_mfma_f32_16x16x32_bf16 %6, v[132:135], v[136:139], %6\n\tv_mfma_f32_16x16x32_bf16 %7, v[132:135], v[136:139], %7\n\t"
+                                 ".endr\n\t"
+                                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                                 : "v"(((const int*)&a)[0]), "v"(((const int*)&a)[1]), "v"(((const int*)&a)[2]), "v"(((const int*)&a)[3]),
+                                   "v"(((const int*)&b)[0]), "v"(((const int*)&b)[1]), "v"(((const int*)&b)[2]), "v"(((const int*)&b)[3])
+                                 : "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139");
+                    __builtin_amdgcn_s_setprio(0);
+                } else if (NEIGH == 3) {                 // a dense main loop: 32 MFMAs back to back at raised priority, operands fetched once per 32 (the conv kernel's K-step)
                     const bf16x8 a = *(const bf16x8*)(lds + ((it * 64 + lane) * 4 & 8188)), b = *(const bf16x8*)(lds + (((it + 7) * 64 + lane) * 4 & 8188));
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -149,7 +165,7 @@ void run(const char* what, int iters) {
     unsigned h[2]; Rec r[16];
     CHECK(hipMemcpy(h, nbad, 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(r, recs, sizeof(r), hipMemcpyDeviceToHost));
     const double checks = (double)nblk * 4 * 64 * 2 * (iters / 2);
-    printf("pair " RPAIR " neighbour %s %-64s gap %d: %u wrong of %.3g half-results (%.1f ms)\n", NEIGH == 0 ? "MFMA" : NEIGH == 1 ? "DPP " : NEIGH == 2 ? "MFMA+DPP" : "dense MFMA", what, GAP, h[0], checks, ms);
+    printf("pair " RPAIR " neighbour %s %-64s gap %d: %u wrong of %.3g half-results (%.1f ms)\n", NEIGH == 0 ? "MFMA" : NEIGH == 1 ? "DPP " : NEIGH == 2 ? "MFMA+DPP" : NEIGH == 3 ? "dense MFMA" : "dense MFMA on v[132:139]", what, GAP, h[0], checks, ms);
     for (unsigned i = 0; i < h[1] && i < 6; ++i)
         printf("      block %d iteration %d lane %d half %d: want %g got %g\n", r[i].blk, r[i].iter, r[i].lane, r[i].half, r[i].want, r[i].got);
     CHECK(hipFree(nbad)); CHECK(hipFree(recs)); CHECK(hipFree(sink));
@@ -171,6 +187,8 @@ int main(int argc, char** argv) {
         run<3, 0, 3>("op_sel:[0,1], pivot by v_mov_b32 (no LDS), 0.0 in the low register", iters / 4);
         run<0, 0, 3>("op_sel:[0,1] (high register -> low lane), ds_bpermute pivot", iters / 4);
         run<1, 0, 3>("op_sel_hi:[1,0] (low register -> high lane), ds_bpermute pivot", iters / 4);
+        run<3, 0, 4>("op_sel:[0,1], pivot by v_mov_b32 (no LDS), 0.0 in the low register", iters / 4);
+        run<0, 0, 4>("op_sel:[0,1] (high register -> low lane), ds_bpermute pivot", iters / 4);
     }
     return 0;
 }
